@@ -1,0 +1,143 @@
+/*
+ * gsr.h — C ABI of the MI355X-native differentiable Gaussian rasterizer (libgsr_hip.so).
+ *
+ * This is the drop-in boundary for the reference's `diff_gaussian_rasterization._C` pybind
+ * module (absent from /root/reference: un-vendored submodule, .gitmodules:4-6).  The
+ * reference binds it at
+ *     gaussian_renderer/__init__.py:15      (import of GaussianRasterizationSettings/GaussianRasterizer)
+ *     gaussian_renderer/__init__.py:42-57   (settings tuple + module construction, every frame)
+ *     gaussian_renderer/__init__.py:257-265 (the call)
+ * and reaches the backward through loss.backward() at train.py:107.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer marked "device" is HIP device memory owned
+ *     by the caller (PyTorch on the Python side); the library never allocates or frees device
+ *     memory and keeps no global mutable state (forward and backward arrive on different OS
+ *     threads: train.py:107 runs backward on an autograd engine thread);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it; the only host
+ *     synchronisation is the read-back of num_rendered in gsr_forward_bin_count();
+ *   - return value 0 = success, >0 = hipError_t, <0 = library error (GSR_E_*); the message is
+ *     available per thread from gsr_last_error();
+ *   - all float tensors are contiguous fp32; matrices are the row-vector-convention 4x4s the
+ *     reference builds at scene/cameras.py:54-57 (p_view = [x,y,z,1] @ viewmatrix).
+ */
+#ifndef GSR_H_
+#define GSR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_ABI_VERSION 1
+
+enum {
+  GSR_OK = 0,
+  GSR_E_BADARG = -1,    /* null / inconsistent arguments (both-or-neither of shs/colors, scales+rotations/cov3D) */
+  GSR_E_CAPACITY = -2,  /* binning workspace smaller than gsr_binning_bytes(num_rendered) */
+  GSR_E_ALIGN = -3,     /* a pointer violates the documented alignment */
+  GSR_E_PREFILTER = -4  /* prefiltered=1 but a Gaussian failed the near-plane cull (debug builds of the check) */
+};
+
+/* One call's inputs.  Replaces the positional arguments of the reference-side
+ * `_C.rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_modifier,
+ * cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, campos,
+ * prefiltered, debug)` implied by gaussian_renderer/__init__.py:42-55,257-265. */
+typedef struct GsrParams {
+  int32_t P;              /* number of Gaussians */
+  int32_t M;              /* SH coefficients stored per Gaussian in `shs` ((max_sh_degree+1)^2); 0 with colors_precomp */
+  int32_t D;              /* active SH degree evaluated (0..3), settings.sh_degree */
+  int32_t width, height;  /* settings.image_width / image_height */
+  float tan_fovx, tan_fovy;
+  float scale_modifier;
+  int32_t prefiltered;
+  int32_t debug;          /* 1: synchronise and check after every kernel */
+  const float* means3D;        /* device [P,3] */
+  const float* shs;            /* device [P,M,3] or NULL (16-byte aligned) */
+  const float* colors_precomp; /* device [P,3] or NULL */
+  const float* opacities;      /* device [P] (the reference passes [P,1]) */
+  const float* scales;         /* device [P,3] or NULL */
+  const float* rotations;      /* device [P,4] (w,x,y,z) or NULL (16-byte aligned) */
+  const float* cov3D_precomp;  /* device [P,6] (xx,xy,xz,yy,yz,zz) or NULL */
+  const float* viewmatrix;     /* device [16] */
+  const float* projmatrix;     /* device [16] */
+  const float* campos;         /* device [3] */
+  const float* bg;             /* device [3] */
+} GsrParams;
+
+/* Gradient outputs of the backward.  Replaces the tuple returned by the reference-side
+ * `_C.rasterize_gaussians_backward(...)`.  Every buffer is written in full by the call
+ * (no caller zero-fill required); NULL is allowed for the members that do not apply
+ * (dL_dshs without shs, dL_dcolors without colors_precomp, dL_dscales/dL_drotations with
+ * cov3D_precomp, dL_dcov3D without it). */
+typedef struct GsrGrads {
+  float* dL_dmeans3D;   /* device [P,3] */
+  float* dL_dmeans2D;   /* device [P,3] (x,y in NDC units scaled by 0.5*W / 0.5*H; z = 0) */
+  float* dL_dshs;       /* device [P,M,3] */
+  float* dL_dcolors;    /* device [P,3] */
+  float* dL_dopacities; /* device [P] */
+  float* dL_dscales;    /* device [P,3] */
+  float* dL_drotations; /* device [P,4] */
+  float* dL_dcov3D;     /* device [P,6] */
+} GsrGrads;
+
+/* ---- introspection ------------------------------------------------------------------ */
+int gsr_abi_version(void);
+const char* gsr_last_error(void);       /* thread-local, never NULL */
+const char* gsr_build_info(void);       /* "gfx950 ..." */
+
+/* ---- workspace sizing (bytes; all workspaces must be 256-byte aligned) ----------------- */
+size_t gsr_geom_bytes(int32_t P);                        /* per-Gaussian state (upstream "geomBuffer") */
+size_t gsr_image_bytes(int32_t width, int32_t height);   /* per-pixel + per-tile state ("imgBuffer") */
+size_t gsr_binning_bytes(uint32_t num_rendered, int32_t width, int32_t height); /* keys/values/sort scratch ("binningBuffer") */
+size_t gsr_backward_bytes(int32_t P, uint32_t num_rendered); /* per-instance gradient rows + flags */
+
+/* ---- forward -------------------------------------------------------------------------- */
+/* Stage 1: preprocess (cull, project, cov3D->cov2D->conic, radius, tile rect, SH->RGB) and the
+ * prefix sum of tiles_touched.  Writes radii[P] (int32) and *num_rendered (host).  Blocks the
+ * calling thread until the 4-byte count has been read back (the one sync of the forward). */
+int gsr_forward_preprocess(const GsrParams* p, void* geom_ws, int32_t* radii, void* stream,
+                           uint32_t* num_rendered);
+
+/* Stage 2: duplicateWithKeys, 64-bit radix sort, identifyTileRanges, per-tile compositing.
+ * Writes out_color[3,H,W].  bin_ws must hold gsr_binning_bytes(num_rendered, W, H). */
+int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t bin_ws_bytes,
+                       void* img_ws, uint32_t num_rendered, float* out_color, void* stream);
+
+/* ---- backward ------------------------------------------------------------------------- */
+int gsr_backward(const GsrParams* p, const int32_t* radii, const void* geom_ws, const void* bin_ws,
+                 const void* img_ws, uint32_t num_rendered, const float* dL_dout_color /* [3,H,W] */,
+                 void* bwd_ws, size_t bwd_ws_bytes, const GsrGrads* grads, void* stream);
+
+/* ---- unit entry points (each stage callable on its own; used by the parity tests) ------- */
+/* keys_out/vals_out receive the result; *_tmp are scratch of the same size; bits sorted: [0,end_bit) */
+size_t gsr_sort_scratch_bytes(uint32_t n);
+int gsr_sort_pairs_u64(uint64_t* keys, uint32_t* vals, uint64_t* keys_tmp, uint32_t* vals_tmp,
+                       uint32_t n, int32_t end_bit, void* scratch, void* stream,
+                       int32_t* result_in_tmp /* host out: 1 if the sorted data ended in *_tmp */);
+/* copies internal state out for inspection (any pointer may be NULL) */
+int gsr_debug_read_geom(const void* geom_ws, int32_t P, float* xy /*[P,2]*/, float* conic_opacity /*[P,4]*/,
+                        float* rgb /*[P,3]*/, float* depth /*[P]*/, uint32_t* tiles_touched /*[P]*/,
+                        uint32_t* point_offsets /*[P]*/, uint32_t* rect /*[P,4] x0,y0,x1,y1*/,
+                        uint32_t* clamped /*[P]*/, void* stream);
+int gsr_debug_read_binning(const void* bin_ws, uint32_t num_rendered, int32_t width, int32_t height,
+                           uint64_t* keys_sorted, uint32_t* point_list, void* stream);
+int gsr_debug_read_image(const void* img_ws, int32_t width, int32_t height, float* final_T,
+                         uint32_t* n_contrib, uint32_t* ranges /*[T,2]*/, void* stream);
+
+/* ---- caller-side steps of the train loop ---------------------------- */
+/* L1 loss (utils/loss_utils.py:17-18) forward + gradient in one pass:
+ * loss_sum[0] += sum|x-gt| (caller zero-fills, divides by n), dL_dx = sign(x-gt) * scale. */
+int gsr_l1_loss_fwd_bwd(const float* x, const float* gt, size_t n, float scale, float* loss_sum,
+                        float* dL_dx, void* stream);
+/* scene/gaussian_model.py:775-777 + train.py:130 fused: for radii>0:
+ * xyz_gradient_accum += ||dL_dmeans2D.xy||, denom += 1, max_radii2D = max(max_radii2D, radii) */
+int gsr_densify_stats(int32_t P, const float* dL_dmeans2D /*[P,3]*/, const int32_t* radii,
+                      float* xyz_gradient_accum, float* denom, float* max_radii2D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H_ */

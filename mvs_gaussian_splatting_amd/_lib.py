@@ -1,0 +1,105 @@
+"""ctypes binding of ``libgsr_hip.so`` (the C ABI declared in ``include/gsr.h``).
+
+There is no CPU fallback: if the shared library is missing or does not load, importing the
+operator raises, and every call on a non-GPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
+
+ABI_VERSION = 1
+
+
+class GsrParams(C.Structure):
+    _fields_ = [
+        ("P", C.c_int32), ("M", C.c_int32), ("D", C.c_int32),
+        ("width", C.c_int32), ("height", C.c_int32),
+        ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("scale_modifier", C.c_float),
+        ("prefiltered", C.c_int32), ("debug", C.c_int32),
+        ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
+        ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
+        ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
+        ("campos", C.c_void_p), ("bg", C.c_void_p),
+    ]
+
+
+class GsrGrads(C.Structure):
+    _fields_ = [
+        ("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
+        ("dL_dcolors", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
+        ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/gsr.h declares
+SYMBOLS = {
+    "gsr_abi_version": (C.c_int, []),
+    "gsr_last_error": (C.c_char_p, []),
+    "gsr_build_info": (C.c_char_p, []),
+    "gsr_geom_bytes": (C.c_size_t, [C.c_int32]),
+    "gsr_image_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "gsr_binning_bytes": (C.c_size_t, [C.c_uint32, C.c_int32, C.c_int32]),
+    "gsr_backward_bytes": (C.c_size_t, [C.c_int32, C.c_uint32]),
+    "gsr_forward_preprocess": (C.c_int, [C.POINTER(GsrParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.POINTER(C.c_uint32)]),
+    "gsr_forward_render": (C.c_int, [C.POINTER(GsrParams), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                     C.c_uint32, C.c_void_p, C.c_void_p]),
+    "gsr_backward": (C.c_int, [C.POINTER(GsrParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                               C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(GsrGrads), C.c_void_p]),
+    "gsr_sort_scratch_bytes": (C.c_size_t, [C.c_uint32]),
+    "gsr_sort_pairs_u64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32,
+                                     C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
+    "gsr_debug_read_geom": (C.c_int, [C.c_void_p, C.c_int32] + [C.c_void_p] * 9),
+    "gsr_debug_read_binning": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]),
+    "gsr_debug_read_image": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]),
+    "gsr_l1_loss_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
+    "gsr_densify_stats": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class GsrError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load (once) and type the library.  Raises ``GsrError`` if it is missing: build it with
+    ``python -c 'import __graft_entry__ as g; g.build()'`` or ``make -C mvs_gaussian_splatting_amd/csrc``."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise GsrError(f"HIP extension not built: {LIB_PATH} is missing (no CPU fallback exists); "
+                           f"run `make -C {os.path.join(_HERE, 'csrc')}`")
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover - depends on the machine
+            raise GsrError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.gsr_abi_version() != ABI_VERSION:
+            raise GsrError(f"ABI mismatch: library {lib.gsr_abi_version()} != binding {ABI_VERSION}")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().gsr_last_error().decode("utf-8", "replace")
+        raise GsrError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,108 @@
+// Caller-side steps of the train loop that sit directly on either side of the rasterizer:
+//   L1 loss + its gradient          utils/loss_utils.py:17-18, train.py:99      
+//   densification statistics        scene/gaussian_model.py:775-777, train.py:130 (§8 a13)
+// plus the unpack kernels behind the gsr_debug_read_* inspection entry points.
+#include "gsr_common.h"
+#include "gsr_launch.h"
+
+namespace gsr {
+
+// loss_sum += sum |x - gt| ; dL_dx = sign(x - gt) * scale.  Streaming, 16 B per lane.
+__global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ x, const float* __restrict__ gt,
+                                                      size_t n, float scale, float* __restrict__ loss_sum,
+                                                      float* __restrict__ dL_dx) {
+  __shared__ float wsum[256 / WAVE];
+  const size_t n4 = n / 4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  float acc = 0.0f;
+  auto sgn = [](float d) { return d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f); };
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 a = reinterpret_cast<const float4*>(x)[i];
+    const float4 b = reinterpret_cast<const float4*>(gt)[i];
+    const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
+    acc += fabsf(d0) + fabsf(d1) + fabsf(d2) + fabsf(d3);
+    if (dL_dx) reinterpret_cast<float4*>(dL_dx)[i] = make_float4(sgn(d0) * scale, sgn(d1) * scale, sgn(d2) * scale, sgn(d3) * scale);
+  }
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float d = x[i] - gt[i];
+    acc += fabsf(d);
+    if (dL_dx) dL_dx[i] = sgn(d) * scale;
+  }
+  acc = wave_reduce_add_f32(acc);
+  if ((threadIdx.x & (WAVE - 1)) == 0) wsum[threadIdx.x / WAVE] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 256 / WAVE; ++w) s += wsum[w];
+    atomicAdd(loss_sum, s);
+  }
+}
+
+__global__ __launch_bounds__(256) void densify_stats_kernel(int P, const float* __restrict__ dL_dmeans2D,
+                                                            const int32_t* __restrict__ radii,
+                                                            float* __restrict__ accum, float* __restrict__ denom,
+                                                            float* __restrict__ max_radii2D) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const int32_t r = radii[i];
+  if (r > 0) {
+    const float gx = dL_dmeans2D[3 * (size_t)i], gy = dL_dmeans2D[3 * (size_t)i + 1];
+    accum[i] += sqrtf(gx * gx + gy * gy);
+    denom[i] += 1.0f;
+    max_radii2D[i] = fmaxf(max_radii2D[i], (float)r);
+  }
+}
+
+__global__ __launch_bounds__(256) void unpack_geom_kernel(int P, const GeomRec* __restrict__ rec,
+                                                          const BinInfo* __restrict__ bin,
+                                                          const uint32_t* __restrict__ offsets, float* xy,
+                                                          float* conic_opacity, float* rgb, float* depth,
+                                                          uint32_t* tiles, uint32_t* point_offsets, uint32_t* rect,
+                                                          uint32_t* clamped) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const BinInfo b = bin[i];
+  const bool vis = b.tiles != 0;
+  GeomRec g;
+  if (vis) g = rec[i];
+  if (xy) { xy[2 * i] = vis ? g.x : 0.f; xy[2 * i + 1] = vis ? g.y : 0.f; }
+  if (conic_opacity) {
+    conic_opacity[4 * i] = vis ? g.cxx : 0.f; conic_opacity[4 * i + 1] = vis ? g.cxy : 0.f;
+    conic_opacity[4 * i + 2] = vis ? g.cyy : 0.f; conic_opacity[4 * i + 3] = vis ? g.opacity : 0.f;
+  }
+  if (rgb) { rgb[3 * i] = vis ? g.r : 0.f; rgb[3 * i + 1] = vis ? g.g : 0.f; rgb[3 * i + 2] = vis ? g.b : 0.f; }
+  if (depth) depth[i] = vis ? b.depth : 0.f;
+  if (tiles) tiles[i] = b.tiles;
+  if (point_offsets) point_offsets[i] = offsets[i];
+  if (rect) {
+    const uint32_t x0 = b.rect_min & 0xffffu, y0 = b.rect_min >> 16;
+    rect[4 * i] = vis ? x0 : 0u; rect[4 * i + 1] = vis ? y0 : 0u;
+    rect[4 * i + 2] = vis ? x0 + (b.rect_wh & 0xffffu) : 0u; rect[4 * i + 3] = vis ? y0 + (b.rect_wh >> 16) : 0u;
+  }
+  if (clamped) clamped[i] = vis ? (g.flags & 7u) : 0u;
+}
+
+
+void launch_l1_loss(const float* x, const float* gt, size_t n, float scale, float* loss_sum, float* dL_dx,
+                    hipStream_t s) {
+  size_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(l1_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, gt, n, scale, loss_sum, dL_dx);
+}
+void launch_densify_stats(int P, const float* dL_dmeans2D, const int32_t* radii, float* accum, float* denom,
+                          float* max_radii2D, hipStream_t s) {
+  if (P <= 0) return;
+  hipLaunchKernelGGL(densify_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, dL_dmeans2D, radii, accum, denom,
+                     max_radii2D);
+}
+void launch_unpack_geom(int P, const GeomRec* rec, const BinInfo* bin, const uint32_t* offsets, float* xy,
+                        float* conic_opacity, float* rgb, float* depth, uint32_t* tiles, uint32_t* point_offsets,
+                        uint32_t* rect, uint32_t* clamped, hipStream_t s) {
+  if (P <= 0) return;
+  hipLaunchKernelGGL(unpack_geom_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, rec, bin, offsets, xy, conic_opacity,
+                     rgb, depth, tiles, point_offsets, rect, clamped);
+}
+
+}  // namespace gsr

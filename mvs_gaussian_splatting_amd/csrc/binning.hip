@@ -1,0 +1,300 @@
+// Tile binning: second level of the tiles_touched scan fused into
+// duplicateWithKeys, a stable LSD radix sort of (u64 key, u32 value) pairs, identifyTileRanges.
+// All integer work: results are bit-exact against oracle/rasterizer_ref.py:bin_ref.
+#include "gsr_common.h"
+#include "gsr_launch.h"
+
+namespace gsr {
+
+// ------------------------------------------------------------------------------------------
+// duplicateWithKeys (A.3).  Block b owns Gaussians [b*256, b*256+256) -- the same partition as
+// the preprocess kernel, so block_offs[b] (exclusive scan of the block totals) + an in-block
+// exclusive scan of `tiles` gives every Gaussian's first slot without a separate scan pass.
+// Emission order: y outer, x inner; key = tile << 32 | bits(depth); value = Gaussian index.
+// Gaussians covering more than DUP_SMALL tiles are emitted by the whole wave cooperatively.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t DUP_SMALL = 16;
+
+__global__ __launch_bounds__(PRE_BLOCK) void duplicate_with_keys_kernel(int P, int grid_x,
+                                                                        const BinInfo* __restrict__ bin,
+                                                                        const uint32_t* __restrict__ block_offs,
+                                                                        GeomRec* __restrict__ rec,
+                                                                        uint32_t* __restrict__ point_offsets,
+                                                                        uint64_t* __restrict__ keys,
+                                                                        uint32_t* __restrict__ vals) {
+  __shared__ uint32_t wave_tot[PRE_BLOCK / WAVE];
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+  const int idx = blockIdx.x * PRE_BLOCK + tid;
+  BinInfo bi{0u, 0u, 0.0f, 0u};
+  if (idx < P) bi = bin[idx];
+  const uint32_t inc = wave_incl_scan_u32(bi.tiles);
+  if (lane == WAVE - 1) wave_tot[wid] = inc;
+  __syncthreads();
+  uint32_t base = block_offs[blockIdx.x];
+#pragma unroll
+  for (int w = 0; w < PRE_BLOCK / WAVE; ++w)
+    if (w < wid) base += wave_tot[w];
+  const uint32_t off = base + inc - bi.tiles;   // exclusive
+  if (idx < P) {
+    point_offsets[idx] = off + bi.tiles;        // inclusive scan, as upstream's point_offsets
+    if (bi.tiles) rec[idx].offs_excl = off;
+  }
+  const uint32_t x0 = bi.rect_min & 0xffffu, y0 = bi.rect_min >> 16;
+  const uint32_t w = bi.rect_wh & 0xffffu;
+  const uint64_t dbits = (uint64_t)__float_as_uint(bi.depth);
+
+  if (bi.tiles && bi.tiles <= DUP_SMALL) {
+    uint32_t o = off;
+    const uint32_t h = bi.rect_wh >> 16;
+    for (uint32_t y = y0; y < y0 + h; ++y)
+      for (uint32_t x = x0; x < x0 + w; ++x) {
+        keys[o] = ((uint64_t)(y * (uint32_t)grid_x + x) << 32) | dbits;
+        vals[o] = (uint32_t)idx;
+        ++o;
+      }
+  }
+  // wave-cooperative path for large splats
+  unsigned long long big = __ballot(bi.tiles > DUP_SMALL);
+  while (big) {
+    const int src = __ffsll((long long)big) - 1;
+    big &= big - 1;
+    const uint32_t s_tiles = __shfl(bi.tiles, src, WAVE);
+    const uint32_t s_off = __shfl(off, src, WAVE);
+    const uint32_t s_min = __shfl(bi.rect_min, src, WAVE);
+    const uint32_t s_w = __shfl(w, src, WAVE);
+    const uint32_t s_dbits = __shfl(__float_as_uint(bi.depth), src, WAVE);
+    const uint32_t s_idx = (uint32_t)(idx - lane + src);
+    const uint32_t sx0 = s_min & 0xffffu, sy0 = s_min >> 16;
+    for (uint32_t k = (uint32_t)lane; k < s_tiles; k += WAVE) {
+      const uint32_t y = sy0 + k / s_w, x = sx0 + k % s_w;
+      keys[s_off + k] = ((uint64_t)(y * (uint32_t)grid_x + x) << 32) | (uint64_t)s_dbits;
+      vals[s_off + k] = s_idx;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Radix sort, one 8-bit digit per pass, three kernels per pass (no inter-workgroup waiting):
+//   hist    : per-block digit histogram      -> hist[digit][block]
+//   rowscan : exclusive scan of every digit row over blocks, row totals -> totals[digit]
+//   scatter : stable local ranking (wave match + LDS), exchange through LDS so that each
+//             digit's run is written contiguously, global offset = digit base + row prefix.
+// Item order inside a block tile: wave w owns [w*1024, w*1024+1024); item i of lane l is
+// element i*64 + l of that range, so (i, l) lexicographic == memory order (stability).
+// ------------------------------------------------------------------------------------------
+__device__ inline uint32_t digit_of(uint64_t k, int shift) { return (uint32_t)(k >> shift) & (RADIX - 1); }
+
+__global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint64_t* __restrict__ keys, uint32_t n,
+                                                                  int shift, uint32_t nblocks,
+                                                                  uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[RADIX];
+  const int tid = threadIdx.x;
+  h[tid] = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * SORT_TILE;
+#pragma unroll 4
+  for (int i = 0; i < SORT_ITEMS; ++i) {
+    const uint32_t g = base + i * SORT_THREADS + tid;
+    if (g < n) atomicAdd(&h[digit_of(keys[g], shift)], 1u);
+  }
+  __syncthreads();
+  hist[(size_t)tid * nblocks + blockIdx.x] = h[tid];
+}
+
+// one block per digit row
+__global__ __launch_bounds__(256) void radix_rowscan_kernel(uint32_t* __restrict__ hist, uint32_t nblocks,
+                                                            uint32_t* __restrict__ totals) {
+  __shared__ uint32_t wave_tot[256 / WAVE];
+  __shared__ uint32_t carry_s;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+  uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t b0 = 0; b0 < nblocks; b0 += 256) {
+    const uint32_t i = b0 + tid;
+    const uint32_t v = i < nblocks ? row[i] : 0u;
+    const uint32_t inc = wave_incl_scan_u32(v);
+    if (lane == WAVE - 1) wave_tot[wid] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+#pragma unroll
+    for (int w = 0; w < 256 / WAVE; ++w)
+      if (w < wid) woff += wave_tot[w];
+    const uint32_t carry = carry_s;
+    if (i < nblocks) row[i] = carry + woff + inc - v;
+    __syncthreads();
+    if (tid == 255) carry_s = carry + woff + inc;
+    __syncthreads();
+  }
+  if (tid == 0) totals[blockIdx.x] = carry_s;
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
+    const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t* __restrict__ keys_out,
+    uint32_t* __restrict__ vals_out, uint32_t n, int shift, uint32_t nblocks, const uint32_t* __restrict__ hist,
+    const uint32_t* __restrict__ totals) {
+  constexpr int NW = SORT_THREADS / WAVE;
+  __shared__ uint64_t xkeys[SORT_TILE];
+  __shared__ uint32_t xvals[SORT_TILE];
+  __shared__ uint32_t wave_hist[NW][RADIX];   // per-wave digit counts, then exclusive wave prefixes
+  __shared__ uint32_t digit_start[RADIX];     // first local slot of every digit
+  __shared__ uint32_t global_base[RADIX];     // global position of the block's first item of the digit
+  __shared__ uint32_t scan_tmp[NW];
+
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+  const uint32_t base = blockIdx.x * SORT_TILE;
+  const uint32_t wbase = base + wid * (WAVE * SORT_ITEMS);
+
+#pragma unroll
+  for (int w = 0; w < NW; ++w) wave_hist[w][tid] = 0;
+  __syncthreads();
+
+  uint64_t k[SORT_ITEMS];
+  uint32_t v[SORT_ITEMS];
+  uint32_t rank[SORT_ITEMS];
+#pragma unroll
+  for (int i = 0; i < SORT_ITEMS; ++i) {
+    const uint32_t g = wbase + i * WAVE + lane;
+    const bool ok = g < n;
+    k[i] = ok ? keys_in[g] : ~0ull;
+    v[i] = ok ? vals_in[g] : 0u;
+  }
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int i = 0; i < SORT_ITEMS; ++i) {
+    const uint32_t g = wbase + i * WAVE + lane;
+    const bool ok = g < n;
+    const uint32_t d = digit_of(k[i], shift);
+    // lanes of this wave holding the same digit (padding lanes never match real ones)
+    unsigned long long peers = __ballot(ok);
+    if (!ok) peers = ~peers;
+#pragma unroll
+    for (int b = 0; b < RADIX_BITS; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long bal = __ballot(bit);
+      peers &= bit ? bal : ~bal;
+    }
+    const uint32_t cnt = (uint32_t)__popcll(peers);
+    const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
+    uint32_t old = 0;
+    if (ok) {
+      old = wave_hist[wid][d];                       // every peer reads before the leader writes:
+      if (before == 0) wave_hist[wid][d] = old + cnt;  // LDS ops of one wave execute in order
+    }
+    rank[i] = old + before;
+  }
+  __syncthreads();
+
+  // digit totals over the 4 waves -> exclusive wave prefixes + block-wide exclusive scan
+  {
+    uint32_t run = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const uint32_t c = wave_hist[w][tid];
+      wave_hist[w][tid] = run;
+      run += c;
+    }
+    const uint32_t inc = wave_incl_scan_u32(run);
+    if (lane == WAVE - 1) scan_tmp[wid] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+      if (w < wid) woff += scan_tmp[w];
+    const uint32_t excl = woff + inc - run;
+    digit_start[tid] = excl;
+    // global base: all smaller digits everywhere + this digit in earlier blocks
+    uint32_t t_inc = wave_incl_scan_u32(totals[tid]);
+    __syncthreads();
+    if (lane == WAVE - 1) scan_tmp[wid] = t_inc;
+    __syncthreads();
+    uint32_t toff = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+      if (w < wid) toff += scan_tmp[w];
+    global_base[tid] = toff + t_inc - totals[tid] + hist[(size_t)tid * nblocks + blockIdx.x];
+  }
+  __syncthreads();
+
+  // exchange: local slot = digit_start + (items of the digit in earlier waves) + rank in wave
+#pragma unroll
+  for (int i = 0; i < SORT_ITEMS; ++i) {
+    const uint32_t g = wbase + i * WAVE + lane;
+    if (g < n) {
+      const uint32_t d = digit_of(k[i], shift);
+      const uint32_t slot = digit_start[d] + wave_hist[wid][d] + rank[i];
+      xkeys[slot] = k[i];
+      xvals[slot] = v[i];
+    }
+  }
+  __syncthreads();
+  const uint32_t count = min((uint32_t)SORT_TILE, n - base);
+#pragma unroll
+  for (int i = 0; i < SORT_ITEMS; ++i) {
+    const uint32_t s = i * SORT_THREADS + tid;
+    if (s < count) {
+      const uint64_t kk = xkeys[s];
+      const uint32_t d = digit_of(kk, shift);
+      const uint32_t dst = global_base[d] + (s - digit_start[d]);
+      keys_out[dst] = kk;
+      vals_out[dst] = xvals[s];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// identifyTileRanges (A.3): ranges[tile] = [first, last+1) of its run in the sorted keys.
+// The caller zero-fills `ranges` (empty tiles stay (0,0)).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void identify_tile_ranges_kernel(uint32_t R, const uint64_t* __restrict__ keys,
+                                                                   uint2* __restrict__ ranges) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= R) return;
+  const uint32_t cur = (uint32_t)(keys[i] >> 32);
+  if (i == 0) {
+    ranges[cur].x = 0;
+  } else {
+    const uint32_t prev = (uint32_t)(keys[i - 1] >> 32);
+    if (cur != prev) {
+      ranges[prev].y = i;
+      ranges[cur].x = i;
+    }
+  }
+  if (i == R - 1) ranges[cur].y = R;
+}
+
+
+void launch_duplicate_with_keys(int P, int grid_x, const BinInfo* bin, const uint32_t* block_offs, GeomRec* rec,
+                                uint32_t* point_offsets, uint64_t* keys, uint32_t* vals, hipStream_t s) {
+  const int nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+  if (nb > 0)
+    hipLaunchKernelGGL(duplicate_with_keys_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, P, grid_x, bin, block_offs, rec,
+                       point_offsets, keys, vals);
+}
+
+bool launch_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, uint32_t n,
+                       int end_bit, void* scratch, hipStream_t s) {
+  if (n == 0 || end_bit <= 0) return false;
+  const SortLayout L(n);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + L.hist);
+  uint32_t* totals = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + L.totals);
+  const int passes = sort_passes(end_bit);
+  uint64_t* kin = keys_a; uint32_t* vin = vals_a; uint64_t* kout = keys_b; uint32_t* vout = vals_b;
+  for (int pass = 0; pass < passes; ++pass) {
+    const int shift = pass * RADIX_BITS;
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(L.nblocks), dim3(SORT_THREADS), 0, s, kin, n, shift, L.nblocks, hist);
+    hipLaunchKernelGGL(radix_rowscan_kernel, dim3(RADIX), dim3(256), 0, s, hist, L.nblocks, totals);
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(L.nblocks), dim3(SORT_THREADS), 0, s, kin, vin, kout, vout, n, shift,
+                       L.nblocks, hist, totals);
+    uint64_t* tk = kin; kin = kout; kout = tk;
+    uint32_t* tv = vin; vin = vout; vout = tv;
+  }
+  return (passes & 1) != 0;
+}
+
+void launch_identify_tile_ranges(uint32_t R, const uint64_t* keys, uint2* ranges, hipStream_t s) {
+  if (R == 0) return;
+  hipLaunchKernelGGL(identify_tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, keys, ranges);
+}
+
+}  // namespace gsr

@@ -1,0 +1,247 @@
+// extern "C" entry points of libgsr_hip.so (declared in include/gsr.h).  Host logic only:
+// argument validation, workspace carving, kernel sequencing on the caller's stream.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+
+#include "gsr_common.h"
+#include "gsr_launch.h"
+
+using namespace gsr;
+
+namespace {
+thread_local std::string g_err = "";
+
+int fail(int code, const char* msg) {
+  g_err = msg;
+  return code;
+}
+int hip_fail(hipError_t e, const char* where) {
+  g_err = std::string(where) + ": " + hipGetErrorString(e);
+  return (int)e;
+}
+#define GSR_HIP(expr)                                        \
+  do {                                                       \
+    hipError_t _e = (expr);                                  \
+    if (_e != hipSuccess) return hip_fail(_e, #expr);        \
+  } while (0)
+
+// after a batch of launches: surface launch errors; in debug mode also synchronise
+int check(const GsrParams* p, hipStream_t s, const char* where) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, where);
+  if (p && p->debug) {
+    e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return hip_fail(e, where);
+  }
+  return 0;
+}
+
+int validate(const GsrParams* p) {
+  if (!p) return fail(GSR_E_BADARG, "params is NULL");
+  if (p->P < 0 || p->width <= 0 || p->height <= 0) return fail(GSR_E_BADARG, "bad P / image size");
+  if (p->width > 65535 * TILE || p->height > 65535 * TILE) return fail(GSR_E_BADARG, "image too large");
+  if (p->P == 0) return 0;
+  if (!p->means3D || !p->opacities || !p->viewmatrix || !p->projmatrix || !p->bg)
+    return fail(GSR_E_BADARG, "means3D / opacities / viewmatrix / projmatrix / bg must be non-NULL");
+  if ((p->shs == nullptr) == (p->colors_precomp == nullptr))
+    return fail(GSR_E_BADARG, "provide exactly one of shs / colors_precomp");
+  const bool sr = p->scales != nullptr || p->rotations != nullptr;
+  if (sr && (p->scales == nullptr || p->rotations == nullptr))
+    return fail(GSR_E_BADARG, "scales and rotations must be given together");
+  if (sr == (p->cov3D_precomp != nullptr))
+    return fail(GSR_E_BADARG, "provide exactly one of (scales, rotations) / cov3D_precomp");
+  if (p->shs) {
+    if (p->D < 0 || p->D > 3) return fail(GSR_E_BADARG, "sh degree must be 0..3");
+    if (p->M < (p->D + 1) * (p->D + 1)) return fail(GSR_E_BADARG, "M smaller than (D+1)^2");
+    if (!p->campos) return fail(GSR_E_BADARG, "campos required with shs");
+    if (((uintptr_t)p->shs & 15u) != 0 && p->M == 16) return fail(GSR_E_ALIGN, "shs must be 16-byte aligned");
+  }
+  if (p->rotations && ((uintptr_t)p->rotations & 15u) != 0) return fail(GSR_E_ALIGN, "rotations must be 16-byte aligned");
+  return 0;
+}
+
+template <typename T>
+T* at(void* base, size_t off) { return reinterpret_cast<T*>(static_cast<char*>(base) + off); }
+template <typename T>
+const T* at(const void* base, size_t off) { return reinterpret_cast<const T*>(static_cast<const char*>(base) + off); }
+
+bool sorted_in_b(int W, int H) {
+  const ImageLayout I(W, H);
+  return (sort_passes(32 + tile_bits(I.tiles)) & 1) != 0;
+}
+}  // namespace
+
+extern "C" {
+
+int gsr_abi_version(void) { return GSR_ABI_VERSION; }
+const char* gsr_last_error(void) { return g_err.c_str(); }
+const char* gsr_build_info(void) { return "libgsr_hip gfx950 wave64 tile16 radix8 (HIP " __DATE__ ")"; }
+
+size_t gsr_geom_bytes(int32_t P) { return GeomLayout(P < 0 ? 0 : P).bytes; }
+size_t gsr_image_bytes(int32_t width, int32_t height) { return ImageLayout(width, height).bytes; }
+size_t gsr_binning_bytes(uint32_t num_rendered, int32_t, int32_t) { return BinLayout(num_rendered).bytes; }
+size_t gsr_backward_bytes(int32_t P, uint32_t num_rendered) { return BwdLayout(P, num_rendered).bytes; }
+size_t gsr_sort_scratch_bytes(uint32_t n) { return SortLayout(n).bytes; }
+
+int gsr_forward_preprocess(const GsrParams* p, void* geom_ws, int32_t* radii, void* stream, uint32_t* num_rendered) {
+  if (int rc = validate(p)) return rc;
+  if (!num_rendered) return fail(GSR_E_BADARG, "num_rendered is NULL");
+  *num_rendered = 0;
+  if (p->P == 0) return 0;
+  if (!geom_ws || !radii) return fail(GSR_E_BADARG, "geom_ws / radii is NULL");
+  if (((uintptr_t)geom_ws & 255u) != 0) return fail(GSR_E_ALIGN, "geom_ws must be 256-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const GeomLayout L(p->P);
+  launch_preprocess_fwd(*p, at<GeomRec>(geom_ws, L.rec), at<BinInfo>(geom_ws, L.bin), at<uint32_t>(geom_ws, L.block_sums),
+                        radii, s);
+  if (int rc = check(p, s, "preprocess_fwd")) return rc;
+  launch_scan_block_sums(at<uint32_t>(geom_ws, L.block_sums), at<uint32_t>(geom_ws, L.block_offs),
+                         at<uint32_t>(geom_ws, L.total), L.nblocks, s);
+  if (int rc = check(p, s, "scan_block_sums")) return rc;
+  GSR_HIP(hipMemcpyAsync(num_rendered, at<uint32_t>(geom_ws, L.total), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  GSR_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t bin_ws_bytes, void* img_ws,
+                       uint32_t R, float* out_color, void* stream) {
+  if (int rc = validate(p)) return rc;
+  if (!img_ws || !out_color) return fail(GSR_E_BADARG, "img_ws / out_color is NULL");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const ImageLayout I(p->width, p->height);
+  uint2* ranges = at<uint2>(img_ws, I.ranges);
+  GSR_HIP(hipMemsetAsync(ranges, 0, 8 * (size_t)I.tiles, s));
+  const uint32_t* point_list = nullptr;
+  const GeomRec* rec = nullptr;
+  if (p->P > 0 && R > 0) {
+    if (!geom_ws || !bin_ws) return fail(GSR_E_BADARG, "geom_ws / bin_ws is NULL");
+    const BinLayout B(R);
+    if (bin_ws_bytes < B.bytes) return fail(GSR_E_CAPACITY, "binning workspace too small for num_rendered");
+    if (((uintptr_t)bin_ws & 255u) != 0) return fail(GSR_E_ALIGN, "bin_ws must be 256-byte aligned");
+    const GeomLayout L(p->P);
+    uint64_t* ka = at<uint64_t>(bin_ws, B.keys_a);
+    uint64_t* kb = at<uint64_t>(bin_ws, B.keys_b);
+    uint32_t* va = at<uint32_t>(bin_ws, B.vals_a);
+    uint32_t* vb = at<uint32_t>(bin_ws, B.vals_b);
+    rec = at<GeomRec>(geom_ws, L.rec);
+    launch_duplicate_with_keys(p->P, I.grid_x, at<BinInfo>(geom_ws, L.bin), at<uint32_t>(geom_ws, L.block_offs),
+                               at<GeomRec>(geom_ws, L.rec), at<uint32_t>(geom_ws, L.offsets), ka, va, s);
+    if (int rc = check(p, s, "duplicate_with_keys")) return rc;
+    const bool in_b = launch_sort_pairs(ka, va, kb, vb, R, 32 + tile_bits(I.tiles), at<char>(bin_ws, B.sort), s);
+    if (int rc = check(p, s, "sort_pairs")) return rc;
+    launch_identify_tile_ranges(R, in_b ? kb : ka, ranges, s);
+    if (int rc = check(p, s, "identify_tile_ranges")) return rc;
+    point_list = in_b ? vb : va;
+  }
+  launch_render_fwd(p->width, p->height, ranges, point_list, rec, p->bg, out_color, at<float>(img_ws, I.final_T),
+                    at<uint32_t>(img_ws, I.n_contrib), at<uint32_t>(img_ws, I.tile_max), s);
+  return check(p, s, "render_fwd");
+}
+
+int gsr_backward(const GsrParams* p, const int32_t* radii, const void* geom_ws, const void* bin_ws, const void* img_ws,
+                 uint32_t R, const float* dL_dout_color, void* bwd_ws, size_t bwd_ws_bytes, const GsrGrads* grads,
+                 void* stream) {
+  if (int rc = validate(p)) return rc;
+  if (!grads) return fail(GSR_E_BADARG, "grads is NULL");
+  if (p->P == 0) return 0;
+  if (!radii || !geom_ws || !img_ws || !dL_dout_color || !bwd_ws) return fail(GSR_E_BADARG, "NULL workspace / input");
+  if (!grads->dL_dmeans3D || !grads->dL_dmeans2D || !grads->dL_dopacities)
+    return fail(GSR_E_BADARG, "dL_dmeans3D / dL_dmeans2D / dL_dopacities must be non-NULL");
+  if (p->shs && !grads->dL_dshs) return fail(GSR_E_BADARG, "dL_dshs required with shs");
+  if (p->colors_precomp && !grads->dL_dcolors) return fail(GSR_E_BADARG, "dL_dcolors required with colors_precomp");
+  const BwdLayout Wl(p->P, R);
+  if (bwd_ws_bytes < Wl.bytes) return fail(GSR_E_CAPACITY, "backward workspace too small");
+  if (((uintptr_t)bwd_ws & 255u) != 0) return fail(GSR_E_ALIGN, "bwd_ws must be 256-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const GeomLayout L(p->P);
+  const ImageLayout I(p->width, p->height);
+  GradRow* rows = at<GradRow>(bwd_ws, Wl.rows);
+  uint8_t* flags = at<uint8_t>(bwd_ws, Wl.flags);
+  const GeomRec* rec = at<GeomRec>(geom_ws, L.rec);
+  if (R > 0) {
+    if (!bin_ws) return fail(GSR_E_BADARG, "bin_ws is NULL");
+    const BinLayout B(R);
+    const uint32_t* point_list = at<uint32_t>(bin_ws, sorted_in_b(p->width, p->height) ? B.vals_b : B.vals_a);
+    GSR_HIP(hipMemsetAsync(flags, 0, R, s));
+    launch_render_bwd(p->width, p->height, at<uint2>(img_ws, I.ranges), point_list, rec, p->bg,
+                      at<float>(img_ws, I.final_T), at<uint32_t>(img_ws, I.n_contrib), at<uint32_t>(img_ws, I.tile_max),
+                      dL_dout_color, rows, flags, s);
+    if (int rc = check(p, s, "render_bwd")) return rc;
+  }
+  launch_preprocess_bwd(*p, radii, rec, rows, flags, *grads, s);
+  return check(p, s, "preprocess_bwd");
+}
+
+int gsr_sort_pairs_u64(uint64_t* keys, uint32_t* vals, uint64_t* keys_tmp, uint32_t* vals_tmp, uint32_t n,
+                       int32_t end_bit, void* scratch, void* stream, int32_t* result_in_tmp) {
+  if (!result_in_tmp) return fail(GSR_E_BADARG, "result_in_tmp is NULL");
+  *result_in_tmp = 0;
+  if (n == 0) return 0;
+  if (!keys || !vals || !keys_tmp || !vals_tmp || !scratch) return fail(GSR_E_BADARG, "NULL buffer");
+  if (end_bit < 0 || end_bit > 64) return fail(GSR_E_BADARG, "end_bit out of range");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  *result_in_tmp = launch_sort_pairs(keys, vals, keys_tmp, vals_tmp, n, end_bit, scratch, s) ? 1 : 0;
+  return check(nullptr, s, "sort_pairs");
+}
+
+int gsr_debug_read_geom(const void* geom_ws, int32_t P, float* xy, float* conic_opacity, float* rgb, float* depth,
+                        uint32_t* tiles_touched, uint32_t* point_offsets, uint32_t* rect, uint32_t* clamped,
+                        void* stream) {
+  if (!geom_ws || P < 0) return fail(GSR_E_BADARG, "bad geom_ws / P");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const GeomLayout L(P);
+  launch_unpack_geom(P, at<GeomRec>(geom_ws, L.rec), at<BinInfo>(geom_ws, L.bin), at<uint32_t>(geom_ws, L.offsets), xy,
+                     conic_opacity, rgb, depth, tiles_touched, point_offsets, rect, clamped, s);
+  return check(nullptr, s, "unpack_geom");
+}
+
+int gsr_debug_read_binning(const void* bin_ws, uint32_t R, int32_t width, int32_t height, uint64_t* keys_sorted,
+                           uint32_t* point_list, void* stream) {
+  if (R == 0) return 0;
+  if (!bin_ws) return fail(GSR_E_BADARG, "bin_ws is NULL");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const BinLayout B(R);
+  const bool in_b = sorted_in_b(width, height);
+  if (keys_sorted)
+    GSR_HIP(hipMemcpyAsync(keys_sorted, at<uint64_t>(bin_ws, in_b ? B.keys_b : B.keys_a), 8 * (size_t)R,
+                           hipMemcpyDeviceToDevice, s));
+  if (point_list)
+    GSR_HIP(hipMemcpyAsync(point_list, at<uint32_t>(bin_ws, in_b ? B.vals_b : B.vals_a), 4 * (size_t)R,
+                           hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+int gsr_debug_read_image(const void* img_ws, int32_t width, int32_t height, float* final_T, uint32_t* n_contrib,
+                         uint32_t* ranges, void* stream) {
+  if (!img_ws) return fail(GSR_E_BADARG, "img_ws is NULL");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const ImageLayout I(width, height);
+  const size_t px = (size_t)width * height;
+  if (final_T) GSR_HIP(hipMemcpyAsync(final_T, at<float>(img_ws, I.final_T), 4 * px, hipMemcpyDeviceToDevice, s));
+  if (n_contrib) GSR_HIP(hipMemcpyAsync(n_contrib, at<uint32_t>(img_ws, I.n_contrib), 4 * px, hipMemcpyDeviceToDevice, s));
+  if (ranges) GSR_HIP(hipMemcpyAsync(ranges, at<uint32_t>(img_ws, I.ranges), 8 * (size_t)I.tiles, hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+int gsr_l1_loss_fwd_bwd(const float* x, const float* gt, size_t n, float scale, float* loss_sum, float* dL_dx,
+                        void* stream) {
+  if (!x || !gt || !loss_sum) return fail(GSR_E_BADARG, "NULL input");
+  if ((((uintptr_t)x | (uintptr_t)gt | (uintptr_t)dL_dx) & 15u) != 0) return fail(GSR_E_ALIGN, "16-byte alignment required");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  launch_l1_loss(x, gt, n, scale, loss_sum, dL_dx, s);
+  return check(nullptr, s, "l1_loss");
+}
+
+int gsr_densify_stats(int32_t P, const float* dL_dmeans2D, const int32_t* radii, float* xyz_gradient_accum, float* denom,
+                      float* max_radii2D, void* stream) {
+  if (P < 0) return fail(GSR_E_BADARG, "P < 0");
+  if (P == 0) return 0;
+  if (!dL_dmeans2D || !radii || !xyz_gradient_accum || !denom || !max_radii2D) return fail(GSR_E_BADARG, "NULL input");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  launch_densify_stats(P, dL_dmeans2D, radii, xyz_gradient_accum, denom, max_radii2D, s);
+  return check(nullptr, s, "densify_stats");
+}
+
+}  // extern "C"

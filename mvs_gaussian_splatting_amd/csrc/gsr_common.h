@@ -1,0 +1,164 @@
+// Shared device-side definitions for the gfx950 Gaussian rasterizer kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gsr.h"
+
+namespace gsr {
+
+constexpr int TILE = 16;            // tile edge in pixels (SURVEY Appendix A constants)
+constexpr int WAVE = 64;            // gfx950 wavefront
+constexpr float NEAR_Z = 0.2f;
+constexpr float DILATION = 0.3f;
+constexpr float FOV_GUARD = 1.3f;
+constexpr float ALPHA_MAX = 0.99f;
+constexpr float ALPHA_MIN = 1.0f / 255.0f;
+constexpr float T_STOP = 0.0001f;
+
+// Per-Gaussian render record: exactly one 64-byte line, so the per-tile gather in the
+// compositing kernels touches one line per instance.
+struct __attribute__((aligned(64))) GeomRec {
+  float x, y, cxx, cxy;          // pixel-space mean, conic xx / xy
+  float cyy, opacity, r, g;      // conic yy, opacity, colour
+  float b, ext_x, ext_y;         // colour, conservative half-extent of the alpha >= 1/255 ellipse
+  uint32_t offs_excl;            // first slot of this Gaussian in the unsorted instance array
+  uint32_t rect_min;             // tile rect min: x | y << 16
+  uint32_t rect_wh;              // tile rect width | height << 16
+  float depth;                   // view-space z
+  uint32_t flags;                // bit0..2: SH clamp mask (r,g,b)
+};
+static_assert(sizeof(GeomRec) == 64, "GeomRec must be one cache line");
+
+// Compact per-Gaussian binning input (read by duplicateWithKeys without touching GeomRec).
+struct __attribute__((aligned(16))) BinInfo {
+  uint32_t rect_min;   // x | y << 16
+  uint32_t rect_wh;    // w | h << 16
+  float depth;
+  uint32_t tiles;      // w*h, 0 if invisible
+};
+
+// Per-instance gradient row written by the compositing backward, summed per Gaussian by
+// the preprocess backward (atomic-free, bitwise reproducible).
+struct __attribute__((aligned(16))) GradRow {
+  float dmx, dmy, dcxx, dcxy;
+  float dcyy, dop, dr, dg;
+  float db, pad0, pad1, pad2;
+};
+static_assert(sizeof(GradRow) == 48, "GradRow");
+
+__host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+constexpr int PRE_BLOCK = 256;      // Gaussians per preprocess / duplicate block (shared so the
+                                    // hierarchical scan lines up)
+
+// ---- workspace layouts (host + device agree through these helpers) -------------------------
+struct GeomLayout {
+  size_t rec, bin, offsets, block_sums, block_offs, total, bytes;
+  int nblocks;
+  __host__ __device__ explicit GeomLayout(int P) {
+    nblocks = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+    size_t o = 0;
+    rec = o;        o = align_up(o + sizeof(GeomRec) * (size_t)P, 256);
+    bin = o;        o = align_up(o + sizeof(BinInfo) * (size_t)P, 256);
+    offsets = o;    o = align_up(o + 4 * (size_t)P, 256);
+    block_sums = o; o = align_up(o + 4 * (size_t)(nblocks + 1), 256);
+    block_offs = o; o = align_up(o + 4 * (size_t)(nblocks + 1), 256);
+    total = o;      o = align_up(o + 64, 256);
+    bytes = o;
+  }
+};
+
+struct ImageLayout {
+  size_t final_T, n_contrib, ranges, tile_max, bytes;
+  int grid_x, grid_y, tiles;
+  __host__ __device__ ImageLayout(int W, int H) {
+    grid_x = (W + TILE - 1) / TILE;
+    grid_y = (H + TILE - 1) / TILE;
+    tiles = grid_x * grid_y;
+    size_t o = 0;
+    size_t px = (size_t)W * H;
+    final_T = o;   o = align_up(o + 4 * px, 256);
+    n_contrib = o; o = align_up(o + 4 * px, 256);
+    ranges = o;    o = align_up(o + 8 * (size_t)tiles, 256);
+    tile_max = o;  o = align_up(o + 4 * (size_t)tiles, 256);
+    bytes = o;
+  }
+};
+
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_ITEMS = 16;
+constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;   // keys per sort block
+constexpr int RADIX_BITS = 8;
+constexpr int RADIX = 1 << RADIX_BITS;
+
+struct SortLayout {
+  size_t hist, totals, bytes;
+  uint32_t nblocks;
+  __host__ __device__ explicit SortLayout(uint32_t n) {
+    nblocks = (n + SORT_TILE - 1) / SORT_TILE;
+    if (nblocks == 0) nblocks = 1;
+    size_t o = 0;
+    hist = o;   o = align_up(o + 4 * (size_t)RADIX * nblocks, 256);
+    totals = o; o = align_up(o + 4 * (size_t)RADIX, 256);
+    bytes = o;
+  }
+};
+
+struct BinLayout {
+  size_t keys_a, keys_b, vals_a, vals_b, sort, bytes;
+  __host__ __device__ explicit BinLayout(uint32_t R) {
+    size_t n = R ? R : 1;
+    size_t o = 0;
+    keys_a = o; o = align_up(o + 8 * n, 256);
+    keys_b = o; o = align_up(o + 8 * n, 256);
+    vals_a = o; o = align_up(o + 4 * n, 256);
+    vals_b = o; o = align_up(o + 4 * n, 256);
+    sort = o;   o = align_up(o + SortLayout((uint32_t)n).bytes, 256);
+    bytes = o;
+  }
+};
+
+struct BwdLayout {
+  size_t rows, flags, bytes;
+  __host__ __device__ BwdLayout(int P, uint32_t R) {
+    (void)P;
+    size_t n = R ? R : 1;
+    size_t o = 0;
+    rows = o;  o = align_up(o + sizeof(GradRow) * n, 256);
+    flags = o; o = align_up(o + n, 256);
+    bytes = o;
+  }
+};
+
+__host__ __device__ inline int tile_bits(int tiles) {
+  int b = 0;
+  while ((1 << b) < tiles) ++b;   // ceil(log2 T): upstream getHigherMsb equivalent for the sort range
+  return b;
+}
+
+// ---- wave helpers --------------------------------------------------------------------------
+__device__ inline int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0)); }
+
+__device__ inline uint32_t wave_incl_scan_u32(uint32_t v) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    uint32_t o = __shfl_up(v, d, WAVE);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+__device__ inline uint32_t wave_reduce_add_u32(uint32_t v) {
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, WAVE);
+  return v;
+}
+
+__device__ inline float wave_reduce_add_f32(float v) {
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, WAVE);
+  return v;
+}
+
+}  // namespace gsr

@@ -1,0 +1,41 @@
+// Host-side launchers, one per kernel; each is defined next to its kernel so that the
+// translation units can be compiled with different floating-point contraction settings.
+#pragma once
+#include "gsr_common.h"
+
+namespace gsr {
+
+// preprocess.hip
+void launch_preprocess_fwd(const GsrParams& p, GeomRec* rec, BinInfo* bin, uint32_t* block_sums, int32_t* radii,
+                           hipStream_t s);
+void launch_scan_block_sums(const uint32_t* block_sums, uint32_t* block_offs, uint32_t* total, int nb, hipStream_t s);
+void launch_preprocess_bwd(const GsrParams& p, const int32_t* radii, const GeomRec* rec, const GradRow* rows,
+                           const uint8_t* row_flags, const GsrGrads& g, hipStream_t s);
+
+// binning.hip
+void launch_duplicate_with_keys(int P, int grid_x, const BinInfo* bin, const uint32_t* block_offs, GeomRec* rec,
+                                uint32_t* point_offsets, uint64_t* keys, uint32_t* vals, hipStream_t s);
+// returns true when the sorted result ended in (keys_b, vals_b)
+bool launch_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, uint32_t n,
+                       int end_bit, void* scratch, hipStream_t s);
+inline int sort_passes(int end_bit) { return (end_bit + RADIX_BITS - 1) / RADIX_BITS; }
+void launch_identify_tile_ranges(uint32_t R, const uint64_t* keys, uint2* ranges, hipStream_t s);
+
+// render.hip
+void launch_render_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
+                       const float* bg, float* out_color, float* final_T, uint32_t* n_contrib, uint32_t* tile_max,
+                       hipStream_t s);
+void launch_render_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
+                       const float* bg, const float* final_T, const uint32_t* n_contrib, const uint32_t* tile_max,
+                       const float* dL_dpix, GradRow* rows, uint8_t* row_flags, hipStream_t s);
+
+// aux.hip
+void launch_l1_loss(const float* x, const float* gt, size_t n, float scale, float* loss_sum, float* dL_dx,
+                    hipStream_t s);
+void launch_densify_stats(int P, const float* dL_dmeans2D, const int32_t* radii, float* accum, float* denom,
+                          float* max_radii2D, hipStream_t s);
+void launch_unpack_geom(int P, const GeomRec* rec, const BinInfo* bin, const uint32_t* offsets, float* xy,
+                        float* conic_opacity, float* rgb, float* depth, uint32_t* tiles, uint32_t* point_offsets,
+                        uint32_t* rect, uint32_t* clamped, hipStream_t s);
+
+}  // namespace gsr

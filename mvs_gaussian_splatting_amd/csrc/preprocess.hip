@@ -1,0 +1,555 @@
+// Per-Gaussian stages: preprocess forward and preprocess backward (§8 a11).
+// One lane per Gaussian, 256-lane blocks.  Compiled with -ffp-contract=off so that the fp32
+// op sequence equals the CPU oracle's elementwise sequence (oracle/rasterizer_ref.py).
+//
+// Behaviour restated from SURVEY.md Appendix A.2 / A.6 (the upstream CUDA source is absent
+// from /root/reference); Python twins of the sub-steps in the reference:
+//   SH -> RGB   utils/sh_utils.py:57-112, gaussian_renderer/__init__.py:80-84
+//   cov3D       scene/gaussian_model.py:28-32, utils/general_utils.py:64-110
+//   matrices    scene/cameras.py:48-57, utils/graphics_utils.py:22-29
+#include "gsr_common.h"
+#include "gsr_launch.h"
+
+namespace gsr {
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+constexpr float SH_C2_0 = 1.0925484305920792f;
+constexpr float SH_C2_1 = -1.0925484305920792f;
+constexpr float SH_C2_2 = 0.31539156525252005f;
+constexpr float SH_C2_3 = -1.0925484305920792f;
+constexpr float SH_C2_4 = 0.5462742152960396f;
+constexpr float SH_C3_0 = -0.5900435899266435f;
+constexpr float SH_C3_1 = 2.890611442640554f;
+constexpr float SH_C3_2 = -0.4570457994644658f;
+constexpr float SH_C3_3 = 0.3731763325901154f;
+constexpr float SH_C3_4 = -0.4570457994644658f;
+constexpr float SH_C3_5 = 1.445305721320277f;
+constexpr float SH_C3_6 = -0.5900435899266435f;
+
+struct Mat4 { float m[16]; };   // m[4*row + col] of the row-vector-convention tensor
+
+__device__ inline void load_mat(const float* __restrict__ src, Mat4& d) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) d.m[i] = src[i];
+}
+
+// cov3D (xx,xy,xz,yy,yz,zz) = R diag(s^2) R^T, quaternion used as passed (A.2)
+__device__ inline void cov3d_from_scale_rot(float sx, float sy, float sz, float mod, float r, float x, float y,
+                                            float z, float* cov) {
+  const float s0 = mod * sx, s1 = mod * sy, s2 = mod * sz;
+  const float R00 = 1.0f - 2.0f * (y * y + z * z), R01 = 2.0f * (x * y - r * z), R02 = 2.0f * (x * z + r * y);
+  const float R10 = 2.0f * (x * y + r * z), R11 = 1.0f - 2.0f * (x * x + z * z), R12 = 2.0f * (y * z - r * x);
+  const float R20 = 2.0f * (x * z - r * y), R21 = 2.0f * (y * z + r * x), R22 = 1.0f - 2.0f * (x * x + y * y);
+  const float L00 = R00 * s0, L01 = R01 * s1, L02 = R02 * s2;
+  const float L10 = R10 * s0, L11 = R11 * s1, L12 = R12 * s2;
+  const float L20 = R20 * s0, L21 = R21 * s1, L22 = R22 * s2;
+  cov[0] = L00 * L00 + L01 * L01 + L02 * L02;
+  cov[1] = L00 * L10 + L01 * L11 + L02 * L12;
+  cov[2] = L00 * L20 + L01 * L21 + L02 * L22;
+  cov[3] = L10 * L10 + L11 * L11 + L12 * L12;
+  cov[4] = L10 * L20 + L11 * L21 + L12 * L22;
+  cov[5] = L20 * L20 + L21 * L21 + L22 * L22;
+}
+
+// EWA projection intermediates shared by forward and backward.
+struct Proj {
+  float tx, ty, tz;        // clamped view-space point
+  float txtz, tytz;        // unclamped ratios
+  float j00, j02, j11, j12;
+  float A0[3], A1[3];      // rows of J * Wv
+  float a, b, c;           // dilated cov2D
+};
+
+__device__ inline void project_cov(const Mat4& V, float vx, float vy, float vz, const float* cov, float fx,
+                                   float fy, float limx, float limy, Proj& o) {
+  o.tz = vz;
+  o.txtz = vx / vz;
+  o.tytz = vy / vz;
+  o.tx = fminf(limx, fmaxf(-limx, o.txtz)) * vz;
+  o.ty = fminf(limy, fmaxf(-limy, o.tytz)) * vz;
+  o.j00 = fx / vz;
+  o.j02 = -(fx * o.tx) / (vz * vz);
+  o.j11 = fy / vz;
+  o.j12 = -(fy * o.ty) / (vz * vz);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    o.A0[j] = o.j00 * V.m[4 * j + 0] + o.j02 * V.m[4 * j + 2];
+    o.A1[j] = o.j11 * V.m[4 * j + 1] + o.j12 * V.m[4 * j + 2];
+  }
+  const float S[3][3] = {{cov[0], cov[1], cov[2]}, {cov[1], cov[3], cov[4]}, {cov[2], cov[4], cov[5]}};
+  float B0[3], B1[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    B0[j] = o.A0[0] * S[0][j] + o.A0[1] * S[1][j] + o.A0[2] * S[2][j];
+    B1[j] = o.A1[0] * S[0][j] + o.A1[1] * S[1][j] + o.A1[2] * S[2][j];
+  }
+  o.a = (B0[0] * o.A0[0] + B0[1] * o.A0[1] + B0[2] * o.A0[2]) + DILATION;
+  o.b = B0[0] * o.A1[0] + B0[1] * o.A1[1] + B0[2] * o.A1[2];
+  o.c = (B1[0] * o.A1[0] + B1[1] * o.A1[1] + B1[2] * o.A1[2]) + DILATION;
+}
+
+// SH basis in the evaluation order of utils/sh_utils.py:74-100; sh = [M][3] row of one Gaussian.
+template <typename LoadSH>
+__device__ inline void eval_sh(int deg, LoadSH sh, float x, float y, float z, float* out) {
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    float res = SH_C0 * sh(0, ch);
+    if (deg > 0) {
+      res = res - SH_C1 * y * sh(1, ch) + SH_C1 * z * sh(2, ch) - SH_C1 * x * sh(3, ch);
+      if (deg > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        res = res + SH_C2_0 * xy * sh(4, ch) + SH_C2_1 * yz * sh(5, ch) +
+              SH_C2_2 * (2.0f * zz - xx - yy) * sh(6, ch) + SH_C2_3 * xz * sh(7, ch) +
+              SH_C2_4 * (xx - yy) * sh(8, ch);
+        if (deg > 2) {
+          res = res + SH_C3_0 * y * (3.0f * xx - yy) * sh(9, ch) + SH_C3_1 * xy * z * sh(10, ch) +
+                SH_C3_2 * y * (4.0f * zz - xx - yy) * sh(11, ch) +
+                SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh(12, ch) +
+                SH_C3_4 * x * (4.0f * zz - xx - yy) * sh(13, ch) + SH_C3_5 * z * (xx - yy) * sh(14, ch) +
+                SH_C3_6 * x * (xx - 3.0f * yy) * sh(15, ch);
+        }
+      }
+    }
+    out[ch] = res;
+  }
+}
+
+__global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, GeomRec* __restrict__ rec,
+                                                                   BinInfo* __restrict__ bin,
+                                                                   uint32_t* __restrict__ block_sums,
+                                                                   int32_t* __restrict__ radii) {
+  __shared__ uint32_t wave_sums[PRE_BLOCK / WAVE];
+  const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  const int W = p.width, H = p.height;
+  const int grid_x = (W + TILE - 1) / TILE, grid_y = (H + TILE - 1) / TILE;
+  uint32_t tiles = 0;
+
+  if (idx < p.P) {
+    Mat4 V, Mx;
+    load_mat(p.viewmatrix, V);
+    load_mat(p.projmatrix, Mx);
+    const float px = p.means3D[3 * (size_t)idx + 0], py = p.means3D[3 * (size_t)idx + 1],
+                pz = p.means3D[3 * (size_t)idx + 2];
+    const float vx = V.m[0] * px + V.m[4] * py + V.m[8] * pz + V.m[12];
+    const float vy = V.m[1] * px + V.m[5] * py + V.m[9] * pz + V.m[13];
+    const float vz = V.m[2] * px + V.m[6] * py + V.m[10] * pz + V.m[14];
+    int32_t radius = 0;
+    BinInfo bi{0u, 0u, 0.0f, 0u};
+    if (vz > NEAR_Z) {
+      const float hx = Mx.m[0] * px + Mx.m[4] * py + Mx.m[8] * pz + Mx.m[12];
+      const float hy = Mx.m[1] * px + Mx.m[5] * py + Mx.m[9] * pz + Mx.m[13];
+      const float hw = Mx.m[3] * px + Mx.m[7] * py + Mx.m[11] * pz + Mx.m[15];
+      const float p_w = 1.0f / (hw + 0.0000001f);
+      const float ndc_x = hx * p_w, ndc_y = hy * p_w;
+
+      float cov[6];
+      if (p.cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cov[k] = p.cov3D_precomp[6 * (size_t)idx + k];
+      } else {
+        const float4 q = reinterpret_cast<const float4*>(p.rotations)[idx];
+        cov3d_from_scale_rot(p.scales[3 * (size_t)idx], p.scales[3 * (size_t)idx + 1], p.scales[3 * (size_t)idx + 2],
+                             p.scale_modifier, q.x, q.y, q.z, q.w, cov);
+      }
+      const float fx = (float)W / (2.0f * p.tan_fovx), fy = (float)H / (2.0f * p.tan_fovy);
+      Proj pr;
+      project_cov(V, vx, vy, vz, cov, fx, fy, FOV_GUARD * p.tan_fovx, FOV_GUARD * p.tan_fovy, pr);
+      const float det = pr.a * pr.c - pr.b * pr.b;
+      if (det != 0.0f) {
+        const float det_inv = 1.0f / det;
+        const float cxx = pr.c * det_inv, cxy = -pr.b * det_inv, cyy = pr.a * det_inv;
+        const float mid = 0.5f * (pr.a + pr.c);
+        const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float lam = fmaxf(mid + sq, mid - sq);
+        const float rad = ceilf(3.0f * sqrtf(lam));
+        const float mx = ((ndc_x + 1.0f) * (float)W - 1.0f) * 0.5f;
+        const float my = ((ndc_y + 1.0f) * (float)H - 1.0f) * 0.5f;
+        if (__builtin_isfinite(rad) && __builtin_isfinite(mx) && __builtin_isfinite(my)) {
+          // clamp in float before the int cast (C truncation toward zero, then clamp to [0, grid])
+          const float gxf = (float)grid_x, gyf = (float)grid_y;
+          const int x0 = (int)fminf(gxf, fmaxf(0.0f, truncf((mx - rad) / (float)TILE)));
+          const int y0 = (int)fminf(gyf, fmaxf(0.0f, truncf((my - rad) / (float)TILE)));
+          const int x1 = (int)fminf(gxf, fmaxf(0.0f, truncf((mx + rad + (float)(TILE - 1)) / (float)TILE)));
+          const int y1 = (int)fminf(gyf, fmaxf(0.0f, truncf((my + rad + (float)(TILE - 1)) / (float)TILE)));
+          const int area = (x1 - x0) * (y1 - y0);
+          if (area > 0) {
+            float rgb[3];
+            uint32_t flags = 0;
+            if (p.colors_precomp) {
+              rgb[0] = p.colors_precomp[3 * (size_t)idx];
+              rgb[1] = p.colors_precomp[3 * (size_t)idx + 1];
+              rgb[2] = p.colors_precomp[3 * (size_t)idx + 2];
+            } else {
+              const float dx = px - p.campos[0], dy = py - p.campos[1], dz = pz - p.campos[2];
+              const float ln = sqrtf(dx * dx + dy * dy + dz * dz);
+              const float ux = dx / ln, uy = dy / ln, uz = dz / ln;
+              const float* __restrict__ s = p.shs + (size_t)idx * p.M * 3;
+              if (p.M == 16) {
+                float4 v[12];
+                const float4* s4 = reinterpret_cast<const float4*>(s);
+#pragma unroll
+                for (int k = 0; k < 12; ++k) v[k] = s4[k];
+                const float* f = reinterpret_cast<const float*>(v);
+                eval_sh(p.D, [&](int k, int ch) { return f[3 * k + ch]; }, ux, uy, uz, rgb);
+              } else {
+                eval_sh(p.D, [&](int k, int ch) { return s[3 * k + ch]; }, ux, uy, uz, rgb);
+              }
+#pragma unroll
+              for (int ch = 0; ch < 3; ++ch) {
+                rgb[ch] = rgb[ch] + 0.5f;
+                if (rgb[ch] < 0.0f) flags |= 1u << ch;
+                rgb[ch] = fmaxf(rgb[ch], 0.0f);
+              }
+            }
+            const float op = p.opacities[idx];
+            // conservative half-extent of the region where alpha = op*exp(power) can reach 1/255
+            float ext_x = -1.0f, ext_y = -1.0f;
+            if (op >= ALPHA_MIN) {
+              const float t = 2.0f * logf(op * 255.0f) * 1.0001f + 1e-4f;
+              ext_x = sqrtf(t * pr.a) * 1.0001f + 0.01f;
+              ext_y = sqrtf(t * pr.c) * 1.0001f + 0.01f;
+            }
+            radius = (int32_t)rad;
+            tiles = (uint32_t)area;
+            GeomRec g;
+            g.x = mx; g.y = my; g.cxx = cxx; g.cxy = cxy;
+            g.cyy = cyy; g.opacity = op; g.r = rgb[0]; g.g = rgb[1];
+            g.b = rgb[2]; g.ext_x = ext_x; g.ext_y = ext_y; g.offs_excl = 0;
+            g.rect_min = (uint32_t)x0 | ((uint32_t)y0 << 16);
+            g.rect_wh = (uint32_t)(x1 - x0) | ((uint32_t)(y1 - y0) << 16);
+            g.depth = vz; g.flags = flags;
+            rec[idx] = g;
+            bi.rect_min = g.rect_min; bi.rect_wh = g.rect_wh; bi.depth = vz; bi.tiles = tiles;
+          }
+        }
+      }
+    }
+    radii[idx] = radius;
+    bin[idx] = bi;
+  }
+
+  // block total of tiles_touched -> first level of the hierarchical scan (§8 a5)
+  const uint32_t ws = wave_reduce_add_u32(tiles);
+  if ((threadIdx.x & (WAVE - 1)) == 0) wave_sums[threadIdx.x / WAVE] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t s = 0;
+#pragma unroll
+    for (int w = 0; w < PRE_BLOCK / WAVE; ++w) s += wave_sums[w];
+    block_sums[blockIdx.x] = s;
+  }
+}
+
+// Exclusive scan of the per-block totals (single block); writes block_offs[nb] and total.
+__global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t* __restrict__ block_sums,
+                                                                uint32_t* __restrict__ block_offs,
+                                                                uint32_t* __restrict__ total, int nb) {
+  __shared__ uint32_t wave_tot[1024 / WAVE];
+  __shared__ uint32_t carry_s;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += 1024) {
+    const int i = base + tid;
+    const uint32_t v = i < nb ? block_sums[i] : 0u;
+    const uint32_t inc = wave_incl_scan_u32(v);
+    if (lane == WAVE - 1) wave_tot[wid] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wid; ++w) woff += wave_tot[w];
+    const uint32_t carry = carry_s;
+    if (i < nb) block_offs[i] = carry + woff + inc - v;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + woff + inc;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    block_offs[nb] = carry_s;
+    *total = carry_s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// preprocess backward (§8 a11, Appendix A.6): per Gaussian, sums its per-instance gradient rows
+// (written by the compositing backward) in slot order, then chains conic -> cov2D -> cov3D /
+// mean, mean2D -> mean3D, colour -> SH (+ direction), cov3D -> scale / rotation.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(GsrParams p, const int32_t* __restrict__ radii,
+                                                                   const GeomRec* __restrict__ rec,
+                                                                   const GradRow* __restrict__ rows,
+                                                                   const uint8_t* __restrict__ row_flags,
+                                                                   GsrGrads g) {
+  const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  if (idx >= p.P) return;
+  const int M = p.M;
+  float dmean[3] = {0.f, 0.f, 0.f};
+  float dm2x = 0.f, dm2y = 0.f, dop = 0.f;
+  float dcol[3] = {0.f, 0.f, 0.f};
+  float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float dscale[3] = {0.f, 0.f, 0.f};
+  float drot[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool vis = radii[idx] > 0;
+
+  if (vis) {
+    const GeomRec r = rec[idx];
+    // ---- (0) deterministic sum of this Gaussian's instance rows -------------------------
+    const uint32_t n = (r.rect_wh & 0xffffu) * (r.rect_wh >> 16);
+    float dcxx = 0.f, dcxy = 0.f, dcyy = 0.f;
+    for (uint32_t k = 0; k < n; ++k) {
+      const uint32_t s = r.offs_excl + k;
+      if (row_flags[s]) {
+        const GradRow q = rows[s];
+        dm2x += q.dmx; dm2y += q.dmy; dcxx += q.dcxx; dcxy += q.dcxy; dcyy += q.dcyy;
+        dop += q.dop; dcol[0] += q.dr; dcol[1] += q.dg; dcol[2] += q.db;
+      }
+    }
+
+    Mat4 V, Mx;
+    load_mat(p.viewmatrix, V);
+    load_mat(p.projmatrix, Mx);
+    const float px = p.means3D[3 * (size_t)idx + 0], py = p.means3D[3 * (size_t)idx + 1],
+                pz = p.means3D[3 * (size_t)idx + 2];
+    const float vx = V.m[0] * px + V.m[4] * py + V.m[8] * pz + V.m[12];
+    const float vy = V.m[1] * px + V.m[5] * py + V.m[9] * pz + V.m[13];
+    const float vz = V.m[2] * px + V.m[6] * py + V.m[10] * pz + V.m[14];
+
+    float cov[6];
+    float4 q4 = make_float4(1.f, 0.f, 0.f, 0.f);
+    float sc[3] = {0.f, 0.f, 0.f};
+    if (p.cov3D_precomp) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) cov[k] = p.cov3D_precomp[6 * (size_t)idx + k];
+    } else {
+      q4 = reinterpret_cast<const float4*>(p.rotations)[idx];
+      sc[0] = p.scales[3 * (size_t)idx]; sc[1] = p.scales[3 * (size_t)idx + 1]; sc[2] = p.scales[3 * (size_t)idx + 2];
+      cov3d_from_scale_rot(sc[0], sc[1], sc[2], p.scale_modifier, q4.x, q4.y, q4.z, q4.w, cov);
+    }
+    const float fx = (float)p.width / (2.0f * p.tan_fovx), fy = (float)p.height / (2.0f * p.tan_fovy);
+    const float limx = FOV_GUARD * p.tan_fovx, limy = FOV_GUARD * p.tan_fovy;
+    Proj pr;
+    project_cov(V, vx, vy, vz, cov, fx, fy, limx, limy, pr);
+
+    // ---- (i) conic -> cov2D (true-derivative convention for dcxy; 1e-7 as upstream) -------
+    const float a = pr.a, b = pr.b, c = pr.c;
+    const float den = a * c - b * b;
+    const float k2 = 1.0f / (den * den + 0.0000001f);
+    const float dL_da = k2 * (-c * c * dcxx + b * c * dcxy + (den - a * c) * dcyy);
+    const float dL_dc = k2 * (-a * a * dcyy + a * b * dcxy + (den - a * c) * dcxx);
+    const float dL_db = k2 * (2.0f * b * c * dcxx - (den + 2.0f * b * b) * dcxy + 2.0f * a * b * dcyy);
+
+    // ---- (ii) cov2D = A S A^T  ->  dS (6 unique) and dA ------------------------------------
+    const float* A0 = pr.A0;
+    const float* A1 = pr.A1;
+    // dL/dS_jk (full symmetric matrix entry) = dL_da A0j A0k + dL_db A0j A1k + dL_dc A1j A1k ;
+    // unique off-diagonals collect both (j,k) and (k,j).
+    auto dS = [&](int j, int k) { return dL_da * A0[j] * A0[k] + dL_db * A0[j] * A1[k] + dL_dc * A1[j] * A1[k]; };
+    dcov[0] = dS(0, 0);
+    dcov[3] = dS(1, 1);
+    dcov[5] = dS(2, 2);
+    dcov[1] = dS(0, 1) + dS(1, 0);
+    dcov[2] = dS(0, 2) + dS(2, 0);
+    dcov[4] = dS(1, 2) + dS(2, 1);
+    // dL/dA0_j = 2 dL_da (S A0)_j + dL_db (S A1)_j ; dL/dA1_j = 2 dL_dc (S A1)_j + dL_db (S A0)_j
+    const float S[3][3] = {{cov[0], cov[1], cov[2]}, {cov[1], cov[3], cov[4]}, {cov[2], cov[4], cov[5]}};
+    float SA0[3], SA1[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      SA0[j] = S[j][0] * A0[0] + S[j][1] * A0[1] + S[j][2] * A0[2];
+      SA1[j] = S[j][0] * A1[0] + S[j][1] * A1[1] + S[j][2] * A1[2];
+    }
+    float dA0[3], dA1[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      dA0[j] = 2.0f * dL_da * SA0[j] + dL_db * SA1[j];
+      dA1[j] = 2.0f * dL_dc * SA1[j] + dL_db * SA0[j];
+    }
+    // A0_j = j00 V[j][0] + j02 V[j][2] ; A1_j = j11 V[j][1] + j12 V[j][2]
+    float dj00 = 0.f, dj02 = 0.f, dj11 = 0.f, dj12 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      dj00 += dA0[j] * V.m[4 * j + 0];
+      dj02 += dA0[j] * V.m[4 * j + 2];
+      dj11 += dA1[j] * V.m[4 * j + 1];
+      dj12 += dA1[j] * V.m[4 * j + 2];
+    }
+    // j00 = fx/tz ; j02 = -fx tx / tz^2 ; j11 = fy/tz ; j12 = -fy ty / tz^2 ; tx = clamp(vx/vz)*vz
+    const float tz = pr.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+    const float xm = (pr.txtz < -limx || pr.txtz > limx) ? 0.0f : 1.0f;
+    const float ym = (pr.tytz < -limy || pr.tytz > limy) ? 0.0f : 1.0f;
+    const float dtx = -fx / tz2 * dj02;                 // d/d(clamped tx)
+    const float dty = -fy / tz2 * dj12;
+    // clamped tx = clamp(vx/vz) * vz: inside -> tx = vx (d/dvx = 1, d/dvz = 0); outside the guard band
+    // upstream zeroes the tx/ty path entirely (A.6 (ii)), including its lim*vz dependence on vz
+    float dvx = xm * dtx;
+    float dvy = ym * dty;
+    float dvz = -fx / tz2 * dj00 - fy / tz2 * dj11 + (2.0f * fx * pr.tx) / tz3 * dj02 + (2.0f * fy * pr.ty) / tz3 * dj12;
+    // view = [p,1] @ V  ->  dL/dp_i = sum_c V[i][c] dv_c   (assigned, A.6 (ii))
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dmean[i] = V.m[4 * i + 0] * dvx + V.m[4 * i + 1] * dvy + V.m[4 * i + 2] * dvz;
+
+    // ---- (iii) mean2D (NDC units) -> mean3D through p_hom / (w + 1e-7) ----------------------
+    {
+      const float hx = Mx.m[0] * px + Mx.m[4] * py + Mx.m[8] * pz + Mx.m[12];
+      const float hy = Mx.m[1] * px + Mx.m[5] * py + Mx.m[9] * pz + Mx.m[13];
+      const float hw = Mx.m[3] * px + Mx.m[7] * py + Mx.m[11] * pz + Mx.m[15];
+      const float m_w = 1.0f / (hw + 0.0000001f);
+      const float mul1 = hx * m_w * m_w, mul2 = hy * m_w * m_w;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        dmean[i] += (Mx.m[4 * i + 0] * m_w - Mx.m[4 * i + 3] * mul1) * dm2x +
+                    (Mx.m[4 * i + 1] * m_w - Mx.m[4 * i + 3] * mul2) * dm2y;
+      }
+    }
+
+    // ---- (iv) colour -> SH coefficients and view direction ----------------------------------
+    if (p.shs) {
+      float dc[3];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) dc[ch] = ((r.flags >> ch) & 1u) ? 0.0f : dcol[ch];
+      const float dxr = px - p.campos[0], dyr = py - p.campos[1], dzr = pz - p.campos[2];
+      const float ln = sqrtf(dxr * dxr + dyr * dyr + dzr * dzr);
+      const float x = dxr / ln, y = dyr / ln, z = dzr / ln;
+      const float* __restrict__ s = p.shs + (size_t)idx * M * 3;
+      float* __restrict__ ds = g.dL_dshs + (size_t)idx * M * 3;
+      const int deg = p.D;
+      float dRx[3] = {0.f, 0.f, 0.f}, dRy[3] = {0.f, 0.f, 0.f}, dRz[3] = {0.f, 0.f, 0.f};
+      auto emit = [&](int k, float basis) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) ds[3 * k + ch] = basis * dc[ch];
+      };
+      auto dirg = [&](int k, float bx, float by, float bz) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          const float c = s[3 * k + ch];
+          dRx[ch] += bx * c; dRy[ch] += by * c; dRz[ch] += bz * c;
+        }
+      };
+      emit(0, SH_C0);
+      if (deg > 0) {
+        emit(1, -SH_C1 * y); emit(2, SH_C1 * z); emit(3, -SH_C1 * x);
+        dirg(1, 0.f, -SH_C1, 0.f); dirg(2, 0.f, 0.f, SH_C1); dirg(3, -SH_C1, 0.f, 0.f);
+        if (deg > 1) {
+          const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+          emit(4, SH_C2_0 * xy); emit(5, SH_C2_1 * yz); emit(6, SH_C2_2 * (2.0f * zz - xx - yy));
+          emit(7, SH_C2_3 * xz); emit(8, SH_C2_4 * (xx - yy));
+          dirg(4, SH_C2_0 * y, SH_C2_0 * x, 0.f);
+          dirg(5, 0.f, SH_C2_1 * z, SH_C2_1 * y);
+          dirg(6, SH_C2_2 * -2.0f * x, SH_C2_2 * -2.0f * y, SH_C2_2 * 4.0f * z);
+          dirg(7, SH_C2_3 * z, 0.f, SH_C2_3 * x);
+          dirg(8, SH_C2_4 * 2.0f * x, SH_C2_4 * -2.0f * y, 0.f);
+          if (deg > 2) {
+            emit(9, SH_C3_0 * y * (3.0f * xx - yy)); emit(10, SH_C3_1 * xy * z);
+            emit(11, SH_C3_2 * y * (4.0f * zz - xx - yy));
+            emit(12, SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy));
+            emit(13, SH_C3_4 * x * (4.0f * zz - xx - yy)); emit(14, SH_C3_5 * z * (xx - yy));
+            emit(15, SH_C3_6 * x * (xx - 3.0f * yy));
+            dirg(9, SH_C3_0 * 6.0f * xy, SH_C3_0 * (3.0f * xx - 3.0f * yy), 0.f);
+            dirg(10, SH_C3_1 * yz, SH_C3_1 * xz, SH_C3_1 * xy);
+            dirg(11, SH_C3_2 * -2.0f * xy, SH_C3_2 * (4.0f * zz - xx - 3.0f * yy), SH_C3_2 * 8.0f * yz);
+            dirg(12, SH_C3_3 * -6.0f * xz, SH_C3_3 * -6.0f * yz, SH_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy));
+            dirg(13, SH_C3_4 * (4.0f * zz - 3.0f * xx - yy), SH_C3_4 * -2.0f * xy, SH_C3_4 * 8.0f * xz);
+            dirg(14, SH_C3_5 * 2.0f * xz, SH_C3_5 * -2.0f * yz, SH_C3_5 * (xx - yy));
+            dirg(15, SH_C3_6 * (3.0f * xx - 3.0f * yy), SH_C3_6 * -6.0f * xy, 0.f);
+          }
+        }
+      }
+      const int used = (deg + 1) * (deg + 1);
+      for (int k = used; k < M; ++k) emit(k, 0.0f);
+      const float ddx = dRx[0] * dc[0] + dRx[1] * dc[1] + dRx[2] * dc[2];
+      const float ddy = dRy[0] * dc[0] + dRy[1] * dc[1] + dRy[2] * dc[2];
+      const float ddz = dRz[0] * dc[0] + dRz[1] * dc[1] + dRz[2] * dc[2];
+      // through dir = d / |d|
+      const float sum2 = dxr * dxr + dyr * dyr + dzr * dzr;
+      const float inv3 = 1.0f / (ln * sum2);
+      dmean[0] += ((sum2 - dxr * dxr) * ddx - dyr * dxr * ddy - dzr * dxr * ddz) * inv3;
+      dmean[1] += (-dxr * dyr * ddx + (sum2 - dyr * dyr) * ddy - dzr * dyr * ddz) * inv3;
+      dmean[2] += (-dxr * dzr * ddx - dyr * dzr * ddy + (sum2 - dzr * dzr) * ddz) * inv3;
+    }
+
+    // ---- (v) cov3D -> scale, rotation -------------------------------------------------------
+    if (!p.cov3D_precomp) {
+      const float mod = p.scale_modifier;
+      const float qr = q4.x, qx = q4.y, qy = q4.z, qz = q4.w;
+      const float s0 = mod * sc[0], s1 = mod * sc[1], s2 = mod * sc[2];
+      const float R[3][3] = {{1.0f - 2.0f * (qy * qy + qz * qz), 2.0f * (qx * qy - qr * qz), 2.0f * (qx * qz + qr * qy)},
+                             {2.0f * (qx * qy + qr * qz), 1.0f - 2.0f * (qx * qx + qz * qz), 2.0f * (qy * qz - qr * qx)},
+                             {2.0f * (qx * qz - qr * qy), 2.0f * (qy * qz + qr * qx), 1.0f - 2.0f * (qx * qx + qy * qy)}};
+      const float sv[3] = {s0, s1, s2};
+      // Sigma = L L^T, L = R diag(s).  dL/dSigma as a full symmetric matrix G (off-diag halves).
+      const float Gm[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
+                              {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
+                              {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+      // dL/dL = 2 G L
+      float dLm[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          dLm[i][k] = 2.0f * (Gm[i][0] * R[0][k] * sv[k] + Gm[i][1] * R[1][k] * sv[k] + Gm[i][2] * R[2][k] * sv[k]);
+      float dR[3][3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          acc += dLm[i][k] * R[i][k];
+          dR[i][k] = dLm[i][k] * sv[k];
+        }
+        dscale[k] = acc * mod;
+      }
+      // R(q) derivative, quaternion as passed (no normalisation Jacobian, A.6 (v))
+      drot[0] = 2.0f * (qz * (dR[1][0] - dR[0][1]) + qy * (dR[0][2] - dR[2][0]) + qx * (dR[2][1] - dR[1][2]));
+      drot[1] = 2.0f * (qy * (dR[0][1] + dR[1][0]) + qz * (dR[0][2] + dR[2][0]) + qr * (dR[2][1] - dR[1][2])) -
+                4.0f * qx * (dR[1][1] + dR[2][2]);
+      drot[2] = 2.0f * (qx * (dR[0][1] + dR[1][0]) + qr * (dR[0][2] - dR[2][0]) + qz * (dR[1][2] + dR[2][1])) -
+                4.0f * qy * (dR[0][0] + dR[2][2]);
+      drot[3] = 2.0f * (qr * (dR[1][0] - dR[0][1]) + qx * (dR[0][2] + dR[2][0]) + qy * (dR[1][2] + dR[2][1])) -
+                4.0f * qz * (dR[0][0] + dR[1][1]);
+    }
+  } else if (p.shs && g.dL_dshs) {
+    float* __restrict__ ds = g.dL_dshs + (size_t)idx * M * 3;
+    for (int k = 0; k < M * 3; ++k) ds[k] = 0.0f;
+  }
+
+  // ---- write every output row in full (no caller zero-fill needed) ---------------------------
+#pragma unroll
+  for (int i = 0; i < 3; ++i) g.dL_dmeans3D[3 * (size_t)idx + i] = dmean[i];
+  g.dL_dmeans2D[3 * (size_t)idx + 0] = dm2x;
+  g.dL_dmeans2D[3 * (size_t)idx + 1] = dm2y;
+  g.dL_dmeans2D[3 * (size_t)idx + 2] = 0.0f;
+  g.dL_dopacities[idx] = dop;
+  if (g.dL_dcolors) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g.dL_dcolors[3 * (size_t)idx + i] = dcol[i];
+  }
+  if (p.cov3D_precomp) {
+    if (g.dL_dcov3D)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) g.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+  } else {
+    if (g.dL_dscales)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) g.dL_dscales[3 * (size_t)idx + i] = dscale[i];
+    if (g.dL_drotations)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) g.dL_drotations[4 * (size_t)idx + i] = drot[i];
+  }
+}
+
+
+void launch_preprocess_fwd(const GsrParams& p, GeomRec* rec, BinInfo* bin, uint32_t* block_sums, int32_t* radii,
+                           hipStream_t s) {
+  const int nb = (p.P + PRE_BLOCK - 1) / PRE_BLOCK;
+  if (nb > 0) hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, p, rec, bin, block_sums, radii);
+}
+void launch_scan_block_sums(const uint32_t* block_sums, uint32_t* block_offs, uint32_t* total, int nb, hipStream_t s) {
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, block_offs, total, nb);
+}
+void launch_preprocess_bwd(const GsrParams& p, const int32_t* radii, const GeomRec* rec, const GradRow* rows,
+                           const uint8_t* row_flags, const GsrGrads& g, hipStream_t s) {
+  const int nb = (p.P + PRE_BLOCK - 1) / PRE_BLOCK;
+  if (nb > 0) hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, p, radii, rec, rows, row_flags, g);
+}
+
+}  // namespace gsr

@@ -1,0 +1,204 @@
+"""Drop-in operator surface for the reference's ``diff_gaussian_rasterization`` import
+(``gaussian_renderer/__init__.py:15``): ``GaussianRasterizationSettings`` (the 12 fields built at
+``gaussian_renderer/__init__.py:42-55``) and ``GaussianRasterizer`` (constructed at ``:57``, called
+with keyword arguments at ``:257-265``).  The arithmetic runs in ``libgsr_hip.so`` through the C ABI
+of ``include/gsr.h``; PyTorch only owns the memory and the stream.
+
+No CPU path exists: tensors must live on a ROCm device and the HIP library must be built.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None or t.numel() == 0 else t.data_ptr()
+
+
+def _f32c(t: torch.Tensor, name: str, dev: torch.device, align16: bool = False) -> torch.Tensor:
+    if t.device != dev:
+        raise ValueError(f"{name} is on {t.device}, expected {dev}")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    t = t.contiguous()
+    if align16 and t.data_ptr() % 16 != 0:
+        t = t.clone()
+    return t
+
+
+def _require_gpu(t: torch.Tensor) -> torch.device:
+    if not t.is_cuda:
+        raise _lib.GsrError("GaussianRasterizer needs tensors on a ROCm GPU: this build has no CPU path "
+                            f"(means3D is on {t.device})")
+    return t.device
+
+
+def _stream(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _make_params(dev, settings: GaussianRasterizationSettings, means3D, sh, colors_precomp, opacities, scales,
+                 rotations, cov3Ds_precomp):
+    """Returns (GsrParams, keepalive list)."""
+    bg = _f32c(settings.bg, "bg", dev)
+    view = _f32c(settings.viewmatrix, "viewmatrix", dev)
+    proj = _f32c(settings.projmatrix, "projmatrix", dev)
+    campos = _f32c(settings.campos, "campos", dev)
+    if bg.numel() != 3 or view.numel() != 16 or proj.numel() != 16 or campos.numel() != 3:
+        raise ValueError("bg/campos must have 3 elements and viewmatrix/projmatrix 16")
+    P = int(means3D.shape[0])
+    M = int(sh.shape[1]) if sh.numel() else 0
+    p = _lib.GsrParams()
+    p.P, p.M, p.D = P, M, int(settings.sh_degree)
+    p.width, p.height = int(settings.image_width), int(settings.image_height)
+    p.tan_fovx, p.tan_fovy = float(settings.tanfovx), float(settings.tanfovy)
+    p.scale_modifier = float(settings.scale_modifier)
+    p.prefiltered, p.debug = int(bool(settings.prefiltered)), int(bool(settings.debug))
+    p.means3D, p.shs, p.colors_precomp = _ptr(means3D), _ptr(sh), _ptr(colors_precomp)
+    p.opacities, p.scales, p.rotations = _ptr(opacities), _ptr(scales), _ptr(rotations)
+    p.cov3D_precomp = _ptr(cov3Ds_precomp)
+    p.viewmatrix, p.projmatrix, p.campos, p.bg = view.data_ptr(), proj.data_ptr(), campos.data_ptr(), bg.data_ptr()
+    return p, [bg, view, proj, campos]
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings: GaussianRasterizationSettings):
+        lib = _lib.load()
+        dev = _require_gpu(means3D)
+        P = int(means3D.shape[0])
+        means3D = _f32c(means3D, "means3D", dev)
+        sh = _f32c(sh, "shs", dev, align16=True)
+        colors_precomp = _f32c(colors_precomp, "colors_precomp", dev)
+        opacities = _f32c(opacities, "opacities", dev)
+        scales = _f32c(scales, "scales", dev)
+        rotations = _f32c(rotations, "rotations", dev, align16=True)
+        cov3Ds_precomp = _f32c(cov3Ds_precomp, "cov3D_precomp", dev)
+        if opacities.numel() != P:
+            raise ValueError("opacities must have one value per Gaussian")
+        H, W = int(raster_settings.image_height), int(raster_settings.image_width)
+
+        with torch.cuda.device(dev):
+            params, keep = _make_params(dev, raster_settings, means3D, sh, colors_precomp, opacities, scales,
+                                        rotations, cov3Ds_precomp)
+            stream = _stream(dev)
+            geom = torch.empty(lib.gsr_geom_bytes(P), dtype=torch.uint8, device=dev)
+            img = torch.empty(lib.gsr_image_bytes(W, H), dtype=torch.uint8, device=dev)
+            radii = torch.zeros(P, dtype=torch.int32, device=dev)
+            color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+            num_rendered = C.c_uint32(0)
+            try:
+                _lib.check(lib.gsr_forward_preprocess(C.byref(params), geom.data_ptr(), _ptr(radii), stream,
+                                                      C.byref(num_rendered)), "gsr_forward_preprocess")
+                R = int(num_rendered.value)
+                nbytes = lib.gsr_binning_bytes(R, W, H)
+                binning = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                _lib.check(lib.gsr_forward_render(C.byref(params), geom.data_ptr(), binning.data_ptr(), nbytes,
+                                                  img.data_ptr(), R, color.data_ptr(), stream), "gsr_forward_render")
+            except _lib.GsrError:
+                if raster_settings.debug:
+                    torch.save((means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                tuple(raster_settings)), "snapshot_fw.dump")
+                    print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise
+
+        ctx.raster_settings = raster_settings
+        ctx.num_rendered = R
+        ctx.keep = keep
+        ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, geom,
+                              binning, img)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii):
+        lib = _lib.load()
+        (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, geom, binning,
+         img) = ctx.saved_tensors
+        settings = ctx.raster_settings
+        dev = means3D.device
+        P = int(means3D.shape[0])
+        R = ctx.num_rendered
+        grad_out_color = _f32c(grad_out_color, "grad_out_color", dev, align16=True)
+
+        with torch.cuda.device(dev):
+            params, keep = _make_params(dev, settings, means3D, sh, colors_precomp, opacities, scales, rotations,
+                                        cov3Ds_precomp)
+            stream = _stream(dev)
+            new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
+            g_means3D, g_means2D, g_opac = new(P, 3), new(P, 3), new(*opacities.shape)
+            g_sh = new(*sh.shape) if sh.numel() else None
+            g_col = new(P, 3) if colors_precomp.numel() else None
+            g_scales = new(P, 3) if scales.numel() else None
+            g_rot = new(P, 4) if rotations.numel() else None
+            g_cov = new(P, 6) if cov3Ds_precomp.numel() else None
+            grads = _lib.GsrGrads(_ptr(g_means3D), _ptr(g_means2D), _ptr(g_sh), _ptr(g_col), _ptr(g_opac),
+                                  _ptr(g_scales), _ptr(g_rot), _ptr(g_cov))
+            nbytes = lib.gsr_backward_bytes(P, R)
+            bwd_ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            try:
+                _lib.check(lib.gsr_backward(C.byref(params), _ptr(radii), geom.data_ptr(), binning.data_ptr(),
+                                            img.data_ptr(), R, grad_out_color.data_ptr(), bwd_ws.data_ptr(), nbytes,
+                                            C.byref(grads), stream), "gsr_backward")
+            except _lib.GsrError:
+                if settings.debug:
+                    torch.save((means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii,
+                                grad_out_color, tuple(settings)), "snapshot_bw.dump")
+                    print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise
+        del keep
+        return g_means3D, g_means2D, g_sh, g_col, g_opac, g_scales, g_rot, g_cov, None
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    """Same call contract as the module the reference constructs per frame
+    (``gaussian_renderer/__init__.py:57``) and calls at ``:257-265``."""
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        raster_settings = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+           ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        empty = torch.empty(0, dtype=torch.float32, device=means3D.device)
+        shs = empty if shs is None else shs
+        colors_precomp = empty if colors_precomp is None else colors_precomp
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, raster_settings)

@@ -1,0 +1,76 @@
+"""Helpers for the -m gpu parity tests: run the HIP path through the C ABI and read its
+internal state back with the gsr_debug_read_* entry points."""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from mvs_gaussian_splatting_amd import _lib
+from mvs_gaussian_splatting_amd.rasterizer import GaussianRasterizationSettings, _make_params, _ptr
+
+
+def product_settings(cam, bg, sh_degree, dev, scale_modifier=1.0, debug=False):
+    return GaussianRasterizationSettings(
+        int(cam.image_height), int(cam.image_width), math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5),
+        bg.to(dev), scale_modifier, cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev), sh_degree,
+        cam.camera_center.to(dev), False, debug)
+
+
+def forward_with_state(dev, settings, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                       cov3D_precomp=None):
+    """Forward through the C ABI keeping the workspaces; returns a dict of numpy/torch results."""
+    lib = _lib.load()
+    e = torch.empty(0, dtype=torch.float32, device=dev)
+    f = lambda t: e if t is None else t.to(dev).float().contiguous()  # noqa: E731
+    means3D, opacities = f(means3D), f(opacities)
+    shs, colors_precomp, scales, rotations, cov3D_precomp = map(f, (shs, colors_precomp, scales, rotations, cov3D_precomp))
+    P = means3D.shape[0]
+    H, W = settings.image_height, settings.image_width
+    with torch.cuda.device(dev):
+        params, keep = _make_params(dev, settings, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        geom = torch.empty(lib.gsr_geom_bytes(P), dtype=torch.uint8, device=dev)
+        img = torch.empty(lib.gsr_image_bytes(W, H), dtype=torch.uint8, device=dev)
+        radii = torch.zeros(P, dtype=torch.int32, device=dev)
+        color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+        R = C.c_uint32(0)
+        _lib.check(lib.gsr_forward_preprocess(C.byref(params), geom.data_ptr(), radii.data_ptr(), stream, C.byref(R)), "pre")
+        R = int(R.value)
+        nb = lib.gsr_binning_bytes(R, W, H)
+        binning = torch.empty(nb, dtype=torch.uint8, device=dev)
+        _lib.check(lib.gsr_forward_render(C.byref(params), geom.data_ptr(), binning.data_ptr(), nb, img.data_ptr(), R,
+                                          color.data_ptr(), stream), "render")
+        xy = torch.empty(P, 2, device=dev)
+        con = torch.empty(P, 4, device=dev)
+        rgb = torch.empty(P, 3, device=dev)
+        depth = torch.empty(P, device=dev)
+        tiles = torch.empty(P, dtype=torch.int32, device=dev)
+        offs = torch.empty(P, dtype=torch.int32, device=dev)
+        rect = torch.empty(P, 4, dtype=torch.int32, device=dev)
+        clamped = torch.empty(P, dtype=torch.int32, device=dev)
+        _lib.check(lib.gsr_debug_read_geom(geom.data_ptr(), P, xy.data_ptr(), con.data_ptr(), rgb.data_ptr(),
+                                           depth.data_ptr(), tiles.data_ptr(), offs.data_ptr(), rect.data_ptr(),
+                                           clamped.data_ptr(), stream), "read_geom")
+        keys = torch.empty(max(R, 1), dtype=torch.int64, device=dev)
+        plist = torch.empty(max(R, 1), dtype=torch.int32, device=dev)
+        _lib.check(lib.gsr_debug_read_binning(binning.data_ptr(), R, W, H, keys.data_ptr(), plist.data_ptr(), stream), "read_bin")
+        gx, gy = (W + 15) // 16, (H + 15) // 16
+        final_T = torch.empty(H, W, device=dev)
+        n_contrib = torch.empty(H, W, dtype=torch.int32, device=dev)
+        ranges = torch.empty(gx * gy, 2, dtype=torch.int32, device=dev)
+        _lib.check(lib.gsr_debug_read_image(img.data_ptr(), W, H, final_T.data_ptr(), n_contrib.data_ptr(),
+                                            ranges.data_ptr(), stream), "read_img")
+        torch.cuda.synchronize(dev)
+    del keep
+    return {"color": color.cpu(), "radii": radii.cpu(), "R": R, "xy": xy.cpu(), "conic_opacity": con.cpu(),
+            "rgb": rgb.cpu(), "depth": depth.cpu(), "tiles": tiles.cpu().numpy().astype(np.int64),
+            "offsets": offs.cpu().numpy().view(np.uint32), "rect": rect.cpu().numpy().astype(np.int64),
+            "clamped": clamped.cpu().numpy(), "keys": keys[:R].cpu().numpy().view(np.uint64),
+            "point_list": plist[:R].cpu().numpy().view(np.uint32), "final_T": final_T.cpu(),
+            "n_contrib": n_contrib.cpu(), "ranges": ranges.cpu().numpy().astype(np.int64)}
+
+
+def oracle_inputs(model):
+    """(means3D, opacity, shs, scales, rotations) exactly as render() hands them to the operator."""
+    return model.get_xyz, model.get_opacity, model.get_features, model.get_scaling, model.get_rotation
