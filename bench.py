@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path (BASELINE.json): forward Mpixels/s and train-step ms at 1920x1080 on 6 M
+synthetic Gaussians, one view per GPU (weak scaling by independent views; the only collective is the
+4-float loss all-reduce, RCCL over xGMI).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C4|C3|C2] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Two timed regions, each EXACTLY K steps bracketed by barrier + torch.cuda.synchronize() and reduced with
+MAX over ranks:  (A) forward-only render under no_grad  -> `value` (Mpixels/s, whole job);
+                 (B) train step = render + L1 + backward + densification stats (+ loss all-reduce)
+                     -> `ms_per_step`.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+
+
+def algorithmic_bytes(P, M, R, W, H, passes):
+    """SURVEY.md §8(d) model v1, bytes per launch of each stage."""
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    return {
+        "preprocess_fwd": P * (44 + 12 * M + 75),
+        "scan_block_sums": 8 * P,
+        "duplicate_with_keys": 20 * P + 12 * R,
+        "radix_sort": 8 * R + passes * 24 * R,
+        "identify_tile_ranges": 8 * R + 8 * T,
+        "render_fwd": 40 * R + 20 * W * H,
+        "render_bwd": 40 * R + 80 * R + 20 * W * H,
+        "preprocess_bwd": P * (175 + 24 * M),
+    }
+
+
+def cpu_baseline(cfg, seed, budget_tiles=96):
+    """Pure-PyTorch CPU oracle timed on the host cores over a bounded sample of the same workload: full
+    preprocess + full binning, compositing forward (+ L1 + backward) on every k-th tile, extrapolated."""
+    from oracle import RasterSettings, preprocess_ref, bin_ref, render_tiles_ref
+    from mvs_gaussian_splatting_amd.synthetic import make_scene
+    torch.set_num_threads(os.cpu_count() or 1)
+    model, cam, bg, target = make_scene(cfg, seed=seed)
+    st = RasterSettings(cam.image_height, cam.image_width, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0,
+                        cam.world_view_transform, cam.full_proj_transform, cfg.sh_degree, cam.camera_center)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        pre = preprocess_ref(model.get_xyz, model.get_opacity, st, shs=model.get_features,
+                             scales=model.get_scaling, rotations=model.get_rotation)
+        t1 = time.perf_counter()
+        keys, plist, ranges = bin_ref(pre)
+        t2 = time.perf_counter()
+        gx, gy = pre["grid"]
+        n_tiles = gx * gy
+        stride = max(1, int(math.ceil(n_tiles / budget_tiles)))
+        tiles = list(range(stride // 2, n_tiles, stride))
+        t3 = time.perf_counter()
+        render_tiles_ref(pre, plist, ranges, st, tiles=tiles)
+        t4 = time.perf_counter()
+    scale = n_tiles / len(tiles)
+    fwd_s = (t1 - t0) + (t2 - t1) + (t4 - t3) * scale
+    W, H = cfg.width, cfg.height
+    return {
+        "value": W * H / fwd_s / 1e6, "unit": "Mpixels/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": (f"pure-PyTorch fp32 oracle, forward: full preprocess ({t1 - t0:.1f}s) + full binning "
+                   f"({t2 - t1:.1f}s) + compositing of {len(tiles)}/{n_tiles} tiles ({t4 - t3:.1f}s, x{scale:.0f} "
+                   f"extrapolated) -> {fwd_s:.1f}s per 1080p frame"),
+        "fwd_seconds_extrapolated": fwd_s,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C4", choices=["C2", "C3", "C4"])
+    ap.add_argument("--gaussians", type=int, default=None, help="override P (debug only; marks the line invalid)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from mvs_gaussian_splatting_amd import render, l1_loss, add_densification_stats, _lib
+    from mvs_gaussian_splatting_amd.synthetic import CONFIGS, make_scene, PipelineParams
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    cfg = CONFIGS[args.config]
+    P = args.gaussians or cfg.P
+    # every rank: same Gaussians (replicated parameters), its own view  -> weak scaling over views
+    model, cam, bg, target = make_scene(cfg, seed=args.seed, P=P, view=rank, n_views=max(world, 8))
+    model.to(dev)
+    cam.to(dev)
+    bg, target = bg.to(dev), target.to(dev)
+    for p in model.parameters():
+        p.requires_grad_(True)
+    pipe = PipelineParams()
+    W, H = cfg.width, cfg.height
+    M = (cfg.sh_degree + 1) ** 2
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize(dev)
+
+    def fwd_step():
+        with torch.no_grad():
+            return render(cam, model, pipe, bg)
+
+    loss_vec = torch.zeros(4, device=dev)
+
+    def train_step():
+        for p in model.parameters():
+            p.grad = None
+        pkg = render(cam, model, pipe, bg)
+        loss = l1_loss(pkg["render"], target)
+        loss.backward()
+        add_densification_stats(model, pkg["viewspace_points"], pkg["radii"])
+        if world > 1:     # the path's only collective: [loss_sum, l1_sum, n_views, pad]
+            loss_vec[0] = loss.detach(); loss_vec[1] = loss.detach(); loss_vec[2] = 1.0
+            dist.all_reduce(loss_vec, op=dist.ReduceOp.SUM)
+        return pkg, loss
+
+    for _ in range(args.warmup):
+        fwd_step()
+        pkg, loss = train_step()
+    radii = pkg["radii"]
+    visible = int((radii > 0).sum())
+
+    def timed(fn, k):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    K = args.steps
+    prof = _lib.StageProfile()
+    with prof:
+        t_fwd = timed(fwd_step, K)
+        stages_fwd = prof.collect()
+        t_train = timed(train_step, K)
+        stages_train = prof.collect()
+    prof.close()
+
+    # instances of this rank's view: read back from the stage the operator itself ran
+    R = int(getattr(pkg["render"].grad_fn, "num_rendered", 0)) if pkg["render"].grad_fn is not None else 0
+
+    if rank == 0:
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        tb = max(1, (tiles - 1).bit_length())
+        passes = (32 + tb + 7) // 8
+        alg = algorithmic_bytes(P, M, R, W, H, passes)
+        by_kernel = {}
+        for src, n_steps in ((stages_fwd, K), (stages_train, K)):
+            for name, (ms, cnt) in src.items():
+                if cnt:
+                    d = by_kernel.setdefault(name, [0.0, 0])
+                    d[0] += ms; d[1] += cnt
+        table = {}
+        for name, (ms, cnt) in by_kernel.items():
+            avg_ms = ms / cnt
+            gbs = alg[name] / (avg_ms * 1e-3) / 1e9
+            table[name] = {"avg_ms": round(avg_ms, 4), "launches": cnt, "algorithmic_bytes": alg[name],
+                           "achieved_GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+        fwd_names = ["preprocess_fwd", "scan_block_sums", "duplicate_with_keys", "radix_sort", "identify_tile_ranges",
+                     "render_fwd"]
+        dominant = max((n for n in table), key=lambda n: table[n]["avg_ms"] * (1 if n in fwd_names else 0))
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(args.config, {}).get(dominant)
+            except Exception:
+                traffic = None
+        roof = {"kernel": dominant, "bound": "hbm", "achieved": table[dominant]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": table[dominant]["frac_of_hbm_peak"], "traffic": traffic,
+                "avg_launch_ms": table[dominant]["avg_ms"], "algorithmic_bytes_per_launch": alg[dominant]}
+        fwd_ms = t_fwd / K * 1e3
+        train_ms = t_train / K * 1e3
+        line = {
+            "metric": "Mpixels/s fwd + train-step ms @1080p, 6M Gaussians, 1->8 MI355X",
+            "value": round(world * W * H / (t_fwd / K) / 1e6, 2), "unit": "Mpixels/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": round(train_ms, 3), "fwd_ms_per_step": round(fwd_ms, 3),
+            "train_mpixels_per_s": round(world * W * H / (t_train / K) / 1e6, 2),
+            "fwd_fps": round(1e3 / fwd_ms, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {P} Gaussians, SH degree {cfg.sh_degree}, {W}x{H}, one view per GPU; "
+                                   "value = forward-only steps, ms_per_step = render+L1+backward+densify-stats steps",
+                       "gaussians": P, "visible": visible, "instances_R": R, "views_per_step": world,
+                       "valid": args.gaussians is None},
+            "roofline": roof,
+            "roofline_by_kernel": table,
+            "fwd_algorithmic_GB": round(sum(alg[n] for n in fwd_names) / 1e9, 3),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(cfg, args.seed)
+            except Exception as ex:  # noqa: BLE001
+                line["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": os.cpu_count(), "kind": "port",
+                                        "sample": f"failed: {ex!r}"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

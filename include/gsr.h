@@ -65,6 +65,7 @@ typedef struct GsrParams {
   const float* projmatrix;     /* device [16] */
   const float* campos;         /* device [3] */
   const float* bg;             /* device [3] */
+  void* profile;               /* NULL, or a handle from gsr_profile_create(): HIP-event stage timers */
 } GsrParams;
 
 /* Gradient outputs of the backward.  Replaces the tuple returned by the reference-side
@@ -126,6 +127,24 @@ int gsr_debug_read_binning(const void* bin_ws, uint32_t num_rendered, int32_t wi
                            uint64_t* keys_sorted, uint32_t* point_list, void* stream);
 int gsr_debug_read_image(const void* img_ws, int32_t width, int32_t height, float* final_T,
                          uint32_t* n_contrib, uint32_t* ranges /*[T,2]*/, void* stream);
+
+/* forward compositing re-run with work counters; stats = device u64[8], zeroed by the caller:
+ * [0] instances in all tile lists, [1] staged into LDS, [2] visited after the sub-block cull,
+ * [3] sub-block evaluations, [4] evaluations with at least one contributing lane, [5] sum of per-tile last contributor */
+int gsr_debug_render_stats(const GsrParams* p, const void* geom_ws, const void* bin_ws, void* img_ws,
+                           uint32_t num_rendered, float* out_color, unsigned long long* stats, void* stream);
+
+/* ---- stage timers (opt-in; HIP events recorded on the call's stream around each stage) ------ */
+enum {
+  GSR_STAGE_PREPROCESS_FWD = 0, GSR_STAGE_SCAN, GSR_STAGE_DUPLICATE, GSR_STAGE_SORT, GSR_STAGE_RANGES,
+  GSR_STAGE_RENDER_FWD, GSR_STAGE_RENDER_BWD, GSR_STAGE_PREPROCESS_BWD, GSR_STAGE_COUNT
+};
+int gsr_profile_create(void** handle);
+int gsr_profile_destroy(void* handle);
+/* waits for the recorded events, adds their elapsed times into ms_sum[GSR_STAGE_COUNT] and the number of
+ * recorded intervals into counts[GSR_STAGE_COUNT], then clears the handle for reuse */
+int gsr_profile_collect(void* handle, double* ms_sum, uint32_t* counts);
+const char* gsr_stage_name(int32_t stage);
 
 /* ---- caller-side steps of the train loop ---------------------------- */
 /* L1 loss (utils/loss_utils.py:17-18) forward + gradient in one pass:

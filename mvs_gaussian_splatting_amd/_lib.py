@@ -24,7 +24,7 @@ class GsrParams(C.Structure):
         ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
         ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
         ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
-        ("campos", C.c_void_p), ("bg", C.c_void_p),
+        ("campos", C.c_void_p), ("bg", C.c_void_p), ("profile", C.c_void_p),
     ]
 
 
@@ -61,6 +61,12 @@ SYMBOLS = {
                                        C.c_void_p]),
     "gsr_l1_loss_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p,
                                       C.c_void_p]),
+    "gsr_debug_render_stats": (C.c_int, [C.POINTER(GsrParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gsr_profile_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "gsr_profile_destroy": (C.c_int, [C.c_void_p]),
+    "gsr_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
+    "gsr_stage_name": (C.c_char_p, [C.c_int32]),
     "gsr_densify_stats": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
 }
@@ -103,3 +109,46 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().gsr_last_error().decode("utf-8", "replace")
         raise GsrError(f"{what} failed (code {rc}): {msg}")
+
+
+STAGE_COUNT = 8
+_active_profile = threading.local()
+
+
+class StageProfile:
+    """HIP-event stage timers of the C library (``gsr_profile_*``).  While active (``with prof:``) every
+    rasterizer call made from this thread records an event pair around each stage on its stream."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        check(load().gsr_profile_create(C.byref(self._h)), "gsr_profile_create")
+
+    def __enter__(self):
+        _active_profile.h = self._h
+        return self
+
+    def __exit__(self, *exc):
+        _active_profile.h = None
+
+    def collect(self):
+        """-> {stage name: (total ms, intervals)}; blocks on the recorded events and clears them."""
+        lib = load()
+        ms = (C.c_double * STAGE_COUNT)()
+        cnt = (C.c_uint32 * STAGE_COUNT)()
+        check(lib.gsr_profile_collect(self._h, ms, cnt), "gsr_profile_collect")
+        return {lib.gsr_stage_name(i).decode(): (ms[i], cnt[i]) for i in range(STAGE_COUNT)}
+
+    def close(self):
+        if self._h:
+            load().gsr_profile_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def active_profile_handle():
+    return getattr(_active_profile, "h", None)

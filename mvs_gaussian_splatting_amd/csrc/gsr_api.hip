@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <string>
+#include <vector>
 
 #include "gsr_common.h"
 #include "gsr_launch.h"
@@ -62,6 +63,32 @@ int validate(const GsrParams* p) {
   return 0;
 }
 
+// ---- opt-in stage timers: event pairs recorded on the caller's stream ----------------------------
+struct Profile {
+  struct Span { int stage; hipEvent_t a, b; };
+  std::vector<Span> used;
+  std::vector<hipEvent_t> pool;
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+  }
+};
+struct StageTimer {
+  Profile* pr; hipStream_t s; Profile::Span sp;
+  StageTimer(const GsrParams* p, int stage, hipStream_t st) : pr(p ? static_cast<Profile*>(p->profile) : nullptr), s(st) {
+    if (!pr) return;
+    sp.stage = stage; sp.a = pr->get(); sp.b = pr->get();
+    if (sp.a) (void)hipEventRecord(sp.a, s);
+  }
+  ~StageTimer() {
+    if (!pr) return;
+    if (sp.b) (void)hipEventRecord(sp.b, s);
+    pr->used.push_back(sp);
+  }
+};
+
 template <typename T>
 T* at(void* base, size_t off) { return reinterpret_cast<T*>(static_cast<char*>(base) + off); }
 template <typename T>
@@ -94,11 +121,17 @@ int gsr_forward_preprocess(const GsrParams* p, void* geom_ws, int32_t* radii, vo
   if (((uintptr_t)geom_ws & 255u) != 0) return fail(GSR_E_ALIGN, "geom_ws must be 256-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const GeomLayout L(p->P);
-  launch_preprocess_fwd(*p, at<GeomRec>(geom_ws, L.rec), at<BinInfo>(geom_ws, L.bin), at<uint32_t>(geom_ws, L.block_sums),
-                        radii, s);
+  {
+    StageTimer t(p, GSR_STAGE_PREPROCESS_FWD, s);
+    launch_preprocess_fwd(*p, at<GeomRec>(geom_ws, L.rec), at<BinInfo>(geom_ws, L.bin),
+                          at<uint32_t>(geom_ws, L.block_sums), radii, s);
+  }
   if (int rc = check(p, s, "preprocess_fwd")) return rc;
-  launch_scan_block_sums(at<uint32_t>(geom_ws, L.block_sums), at<uint32_t>(geom_ws, L.block_offs),
-                         at<uint32_t>(geom_ws, L.total), L.nblocks, s);
+  {
+    StageTimer t(p, GSR_STAGE_SCAN, s);
+    launch_scan_block_sums(at<uint32_t>(geom_ws, L.block_sums), at<uint32_t>(geom_ws, L.block_offs),
+                           at<uint32_t>(geom_ws, L.total), L.nblocks, s);
+  }
   if (int rc = check(p, s, "scan_block_sums")) return rc;
   GSR_HIP(hipMemcpyAsync(num_rendered, at<uint32_t>(geom_ws, L.total), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   GSR_HIP(hipStreamSynchronize(s));
@@ -126,17 +159,30 @@ int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t b
     uint32_t* va = at<uint32_t>(bin_ws, B.vals_a);
     uint32_t* vb = at<uint32_t>(bin_ws, B.vals_b);
     rec = at<GeomRec>(geom_ws, L.rec);
-    launch_duplicate_with_keys(p->P, I.grid_x, at<BinInfo>(geom_ws, L.bin), at<uint32_t>(geom_ws, L.block_offs),
-                               at<GeomRec>(geom_ws, L.rec), at<uint32_t>(geom_ws, L.offsets), ka, va, s);
+    {
+      StageTimer t(p, GSR_STAGE_DUPLICATE, s);
+      launch_duplicate_with_keys(p->P, I.grid_x, at<BinInfo>(geom_ws, L.bin), at<uint32_t>(geom_ws, L.block_offs),
+                                 at<GeomRec>(geom_ws, L.rec), at<uint32_t>(geom_ws, L.offsets), ka, va, s);
+    }
     if (int rc = check(p, s, "duplicate_with_keys")) return rc;
-    const bool in_b = launch_sort_pairs(ka, va, kb, vb, R, 32 + tile_bits(I.tiles), at<char>(bin_ws, B.sort), s);
+    bool in_b;
+    {
+      StageTimer t(p, GSR_STAGE_SORT, s);
+      in_b = launch_sort_pairs(ka, va, kb, vb, R, 32 + tile_bits(I.tiles), at<char>(bin_ws, B.sort), s);
+    }
     if (int rc = check(p, s, "sort_pairs")) return rc;
-    launch_identify_tile_ranges(R, in_b ? kb : ka, ranges, s);
+    {
+      StageTimer t(p, GSR_STAGE_RANGES, s);
+      launch_identify_tile_ranges(R, in_b ? kb : ka, ranges, s);
+    }
     if (int rc = check(p, s, "identify_tile_ranges")) return rc;
     point_list = in_b ? vb : va;
   }
-  launch_render_fwd(p->width, p->height, ranges, point_list, rec, p->bg, out_color, at<float>(img_ws, I.final_T),
-                    at<uint32_t>(img_ws, I.n_contrib), at<uint32_t>(img_ws, I.tile_max), s);
+  {
+    StageTimer t(p, GSR_STAGE_RENDER_FWD, s);
+    launch_render_fwd(p->width, p->height, ranges, point_list, rec, p->bg, out_color, at<float>(img_ws, I.final_T),
+                      at<uint32_t>(img_ws, I.n_contrib), at<uint32_t>(img_ws, I.tile_max), s);
+  }
   return check(p, s, "render_fwd");
 }
 
@@ -165,13 +211,72 @@ int gsr_backward(const GsrParams* p, const int32_t* radii, const void* geom_ws, 
     const BinLayout B(R);
     const uint32_t* point_list = at<uint32_t>(bin_ws, sorted_in_b(p->width, p->height) ? B.vals_b : B.vals_a);
     GSR_HIP(hipMemsetAsync(flags, 0, R, s));
-    launch_render_bwd(p->width, p->height, at<uint2>(img_ws, I.ranges), point_list, rec, p->bg,
-                      at<float>(img_ws, I.final_T), at<uint32_t>(img_ws, I.n_contrib), at<uint32_t>(img_ws, I.tile_max),
-                      dL_dout_color, rows, flags, s);
+    {
+      StageTimer t(p, GSR_STAGE_RENDER_BWD, s);
+      launch_render_bwd(p->width, p->height, at<uint2>(img_ws, I.ranges), point_list, rec, p->bg,
+                        at<float>(img_ws, I.final_T), at<uint32_t>(img_ws, I.n_contrib),
+                        at<uint32_t>(img_ws, I.tile_max), dL_dout_color, rows, flags, s);
+    }
     if (int rc = check(p, s, "render_bwd")) return rc;
   }
-  launch_preprocess_bwd(*p, radii, rec, rows, flags, *grads, s);
+  {
+    StageTimer t(p, GSR_STAGE_PREPROCESS_BWD, s);
+    launch_preprocess_bwd(*p, radii, rec, rows, flags, *grads, s);
+  }
   return check(p, s, "preprocess_bwd");
+}
+
+int gsr_profile_create(void** handle) {
+  if (!handle) return fail(GSR_E_BADARG, "handle is NULL");
+  *handle = new Profile();
+  return 0;
+}
+int gsr_profile_destroy(void* handle) {
+  Profile* pr = static_cast<Profile*>(handle);
+  if (!pr) return 0;
+  for (auto& sp : pr->used) { if (sp.a) (void)hipEventDestroy(sp.a); if (sp.b) (void)hipEventDestroy(sp.b); }
+  for (auto e : pr->pool) (void)hipEventDestroy(e);
+  delete pr;
+  return 0;
+}
+int gsr_profile_collect(void* handle, double* ms_sum, uint32_t* counts) {
+  Profile* pr = static_cast<Profile*>(handle);
+  if (!pr || !ms_sum || !counts) return fail(GSR_E_BADARG, "NULL argument");
+  for (auto& sp : pr->used) {
+    if (sp.a && sp.b) {
+      GSR_HIP(hipEventSynchronize(sp.b));
+      float ms = 0.f;
+      GSR_HIP(hipEventElapsedTime(&ms, sp.a, sp.b));
+      if (sp.stage >= 0 && sp.stage < GSR_STAGE_COUNT) { ms_sum[sp.stage] += ms; counts[sp.stage] += 1; }
+    }
+    if (sp.a) pr->pool.push_back(sp.a);
+    if (sp.b) pr->pool.push_back(sp.b);
+  }
+  pr->used.clear();
+  return 0;
+}
+const char* gsr_stage_name(int32_t stage) {
+  static const char* names[GSR_STAGE_COUNT] = {"preprocess_fwd", "scan_block_sums", "duplicate_with_keys", "radix_sort",
+                                               "identify_tile_ranges", "render_fwd", "render_bwd", "preprocess_bwd"};
+  return (stage >= 0 && stage < GSR_STAGE_COUNT) ? names[stage] : "?";
+}
+
+// Re-runs the forward compositing with work counters (debug / tuning only):
+// stats[0] instances in all tile lists, [1] instances staged into LDS, [2] instances visited after the
+// sub-block cull, [3] sub-block evaluations, [4] evaluations with >= 1 contributing lane, [5] sum of tile_max.
+int gsr_debug_render_stats(const GsrParams* p, const void* geom_ws, const void* bin_ws, void* img_ws, uint32_t R,
+                           float* out_color, unsigned long long* stats /* device [8], zeroed by caller */, void* stream) {
+  if (int rc = validate(p)) return rc;
+  if (!geom_ws || !bin_ws || !img_ws || !out_color || !stats || R == 0) return fail(GSR_E_BADARG, "NULL argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const ImageLayout I(p->width, p->height);
+  const GeomLayout L(p->P);
+  const BinLayout B(R);
+  launch_render_fwd(p->width, p->height, at<uint2>(img_ws, I.ranges),
+                    at<uint32_t>(bin_ws, sorted_in_b(p->width, p->height) ? B.vals_b : B.vals_a),
+                    at<GeomRec>(geom_ws, L.rec), p->bg, out_color, at<float>(img_ws, I.final_T),
+                    at<uint32_t>(img_ws, I.n_contrib), at<uint32_t>(img_ws, I.tile_max), s, stats);
+  return check(p, s, "render_stats");
 }
 
 int gsr_sort_pairs_u64(uint64_t* keys, uint32_t* vals, uint64_t* keys_tmp, uint32_t* vals_tmp, uint32_t n,

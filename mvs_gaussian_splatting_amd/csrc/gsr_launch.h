@@ -24,7 +24,7 @@ void launch_identify_tile_ranges(uint32_t R, const uint64_t* keys, uint2* ranges
 // render.hip
 void launch_render_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
                        const float* bg, float* out_color, float* final_T, uint32_t* n_contrib, uint32_t* tile_max,
-                       hipStream_t s);
+                       hipStream_t s, unsigned long long* stats = nullptr);
 void launch_render_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
                        const float* bg, const float* final_T, const uint32_t* n_contrib, const uint32_t* tile_max,
                        const float* dL_dpix, GradRow* rows, uint8_t* row_flags, hipStream_t s);

@@ -18,17 +18,29 @@
 namespace gsr {
 
 constexpr int BATCH = WAVE;   // instances staged per round
+constexpr float LOG2E = 1.4426950408889634f;
 
-struct Staged {               // what one lane fetches for the instance it stages
-  float4 q0, q1, q2;          // GeomRec words 0..11
+// What one lane fetches for the instance it stages (GeomRec words 0..11 and, for the backward, 12..13).
+struct Staged {
+  float4 q0, q1, q2;
   uint32_t rect_min, rect_wh;
 };
 
+// FULL = false skips word 11 (offs_excl), which the forward never reads: a dead destination register
+// of an in-flight load gets recycled by the compiler and forces an early s_waitcnt vmcnt.
+template <bool FULL>
 __device__ inline void load_staged(const GeomRec* __restrict__ rec, uint32_t id, Staged& s) {
   const float4* r = reinterpret_cast<const float4*>(rec + id);
   s.q0 = r[0];
   s.q1 = r[1];
-  s.q2 = r[2];
+  if (FULL) {
+    s.q2 = r[2];
+  } else {
+    const float* f = reinterpret_cast<const float*>(r + 2);
+    s.q2.x = f[0];
+    s.q2.y = f[1];
+    s.q2.z = f[2];
+  }
 }
 
 // which of the tile's four 8x8 sub-blocks can the Gaussian reach (bit k = sub-block k)
@@ -42,6 +54,22 @@ __device__ inline uint32_t subblock_mask(float gx, float gy, float ex, float ey,
          ((uint32_t)(xr && yb) << 3);
 }
 
+// LDS image of a staged instance.  The quadratic form is kept pre-scaled by log2(e) so that the
+// exponential is a bare v_exp_f32:  log2e*power = dx*(aq*dx + bq*dy) + cq*dy*dy  with
+// aq = -0.5*log2e*cxx, bq = -log2e*cxy, cq = -0.5*log2e*cyy.
+struct LdsRec {
+  float4 A;   // x, y, aq, bq
+  float4 B;   // cq, opacity, r, g
+};
+__device__ inline void make_lds(const Staged& st, LdsRec& o) {
+  o.A = make_float4(st.q0.x, st.q0.y, (-0.5f * LOG2E) * st.q0.z, -LOG2E * st.q0.w);
+  o.B = make_float4((-0.5f * LOG2E) * st.q1.x, st.q1.y, st.q1.z, st.q1.w);
+}
+
+// Per-lane pixel state: T > 0 while the pixel is live; a pixel that is done (or outside the image)
+// carries T == 0 so that every later test_T = T*(1-alpha) = 0 < 1e-4 keeps it out of the blend,
+// and its final transmittance is parked in Tfin.
+template <bool STATS>
 __global__ __launch_bounds__(WAVE) void render_fwd_kernel(int W, int H, int grid_x,
                                                           const uint2* __restrict__ ranges,
                                                           const uint32_t* __restrict__ point_list,
@@ -50,93 +78,107 @@ __global__ __launch_bounds__(WAVE) void render_fwd_kernel(int W, int H, int grid
                                                           float* __restrict__ out_color,
                                                           float* __restrict__ final_T,
                                                           uint32_t* __restrict__ n_contrib,
-                                                          uint32_t* __restrict__ tile_max) {
-  __shared__ float4 sA[2][BATCH];
-  __shared__ float4 sB[2][BATCH];
-  __shared__ float sC[2][BATCH];
+                                                          uint32_t* __restrict__ tile_max,
+                                                          unsigned long long* __restrict__ stats) {
+  __shared__ float4 sA[BATCH];
+  __shared__ float4 sB[BATCH];
+  __shared__ float sC[BATCH];
 
   const int tile = blockIdx.x;
   const int lane = threadIdx.x;
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
   const int px0 = tile_x * TILE + (lane & 7), py0 = tile_y * TILE + (lane >> 3);
   const float tx0 = (float)(tile_x * TILE), ty0 = (float)(tile_y * TILE);
+  const float pxf0 = (float)px0, pyf0 = (float)py0;
 
-  float pxf[4], pyf[4], T[4], Cr[4], Cg[4], Cb[4];
+  float T[4], Tfin[4], Cr[4], Cg[4], Cb[4];
   uint32_t last[4];
-  bool done[4], inside[4];
+  uint32_t live = 0;   // wave-uniform: bit k set while sub-block k still has a live pixel
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int px = px0 + 8 * (k & 1), py = py0 + 8 * (k >> 1);
-    pxf[k] = (float)px;
-    pyf[k] = (float)py;
-    inside[k] = px < W && py < H;
-    done[k] = !inside[k];
-    T[k] = 1.0f;
+    const bool in = (px0 + 8 * (k & 1)) < W && (py0 + 8 * (k >> 1)) < H;
+    T[k] = in ? 1.0f : 0.0f;
+    Tfin[k] = 1.0f;
     Cr[k] = Cg[k] = Cb[k] = 0.0f;
     last[k] = 0;
+    if (__any(in)) live |= 1u << k;
   }
 
   const uint2 range = ranges[tile];
   const uint32_t start = range.x, end = range.y;
-  bool all_done = __all(done[0] && done[1] && done[2] && done[3]);
 
-  // software pipeline: ids two rounds ahead, records one round ahead
+  // software pipeline: ids two rounds ahead, records one round ahead.  Every prefetch is issued
+  // unconditionally with a clamped index (lanes past the end re-read the last instance and are masked
+  // by `have`): a conditional overwrite of `st` makes the compiler copy registers right behind the load
+  // and wait for it on the spot.
   uint32_t id_next = 0;
   Staged st;
   st.q0 = st.q1 = st.q2 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (start + lane < end) {
-    const uint32_t id = point_list[start + lane];
-    load_staged(rec, id, st);
+  if (start >= end) live = 0;
+  if (live) {
+    load_staged<false>(rec, point_list[min(start + lane, end - 1)], st);
+    id_next = point_list[min(start + BATCH + lane, end - 1)];
   }
-  if (start + BATCH + lane < end) id_next = point_list[start + BATCH + lane];
 
-  int buf = 0;
-  for (uint32_t pos = start; pos < end && !all_done; pos += BATCH) {
+  uint32_t st_staged = 0, st_visited = 0, st_evals = 0, st_hits = 0;
+  for (uint32_t pos = start; pos < end && live; pos += BATCH) {
     const bool have = pos + lane < end;
-    uint32_t m = have ? subblock_mask(st.q0.x, st.q0.y, st.q2.y, st.q2.z, tx0, ty0) : 0u;
-    sA[buf][lane] = st.q0;
-    sB[buf][lane] = st.q1;
-    sC[buf][lane] = st.q2.x;
-    __syncthreads();   // single-wave workgroup: orders the LDS writes before the broadcast reads
+    if (STATS) st_staged += min((uint32_t)BATCH, end - pos);
+    const uint32_t m = have ? subblock_mask(st.q0.x, st.q0.y, st.q2.y, st.q2.z, tx0, ty0) : 0u;
+    LdsRec lr;
+    make_lds(st, lr);
+    __syncthreads();            // single-wave workgroup: previous round's broadcast reads are done
+    sA[lane] = lr.A;
+    sB[lane] = lr.B;
+    sC[lane] = st.q2.x;
+    __syncthreads();
     // prefetch the next round while this one is composited
-    if (pos + BATCH + lane < end) load_staged(rec, id_next, st);
-    if (pos + 2 * BATCH + lane < end) id_next = point_list[pos + 2 * BATCH + lane];
+    load_staged<false>(rec, id_next, st);
+    id_next = point_list[min(pos + 2 * BATCH + lane, end - 1)];
 
     unsigned long long nz = __ballot(m != 0u);
     while (nz) {
       const int j = __ffsll((long long)nz) - 1;
       nz &= nz - 1;
-      const uint32_t mj = (uint32_t)__builtin_amdgcn_readlane((int)m, j);
-      const float4 a = sA[buf][j];
-      const float4 b = sB[buf][j];
-      const float cb = sC[buf][j];
+      const uint32_t mj = (uint32_t)__builtin_amdgcn_readlane((int)m, j) & live;
+      if (mj == 0u) continue;
+      const float4 a = sA[j];
+      const float4 b = sB[j];
+      const float cb = sC[j];
       const uint32_t pos1 = pos - start + (uint32_t)j + 1u;   // 1-based contributor index
+      if (STATS) ++st_visited;
+      const float dx0 = a.x - pxf0, dy0 = a.y - pyf0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (mj & (1u << k)) {
-          const float dx = a.x - pxf[k], dy = a.y - pyf[k];
-          const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-          const float alpha = fminf(ALPHA_MAX, b.y * __expf(power));
-          const bool ok = !done[k] && power <= 0.0f && alpha >= ALPHA_MIN;
+          const float dx = (k & 1) ? dx0 - 8.0f : dx0;
+          const float dy = (k >> 1) ? dy0 - 8.0f : dy0;
+          const float t = fmaf(a.w, dy, a.z * dx);
+          const float p2 = fmaf(dx, t, (b.x * dy) * dy);
+          const float alpha = fminf(ALPHA_MAX, b.y * __builtin_amdgcn_exp2f(p2));
+          const bool ok = (p2 <= 0.0f) && (alpha >= ALPHA_MIN);
           const float test_T = T[k] * (1.0f - alpha);
-          const bool stop = ok && test_T < T_STOP;
-          done[k] = done[k] || stop;
+          const bool stop = ok && (test_T < T_STOP);
+          if (STATS) { ++st_evals; if (__any(ok && T[k] > 0.0f)) ++st_hits; }
           if (ok && !stop) {
             const float w = alpha * T[k];
-            Cr[k] += b.z * w;
-            Cg[k] += b.w * w;
-            Cb[k] += cb * w;
+            Cr[k] = fmaf(b.z, w, Cr[k]);
+            Cg[k] = fmaf(b.w, w, Cg[k]);
+            Cb[k] = fmaf(cb, w, Cb[k]);
             T[k] = test_T;
             last[k] = pos1;
           }
+          if (__any(stop)) {           // rare: some pixel saturates here (or is already parked)
+            if (stop && T[k] > 0.0f) {
+              Tfin[k] = T[k];
+              T[k] = 0.0f;
+            }
+            if (!__any(T[k] > 0.0f)) live &= ~(1u << k);
+          }
         }
       }
-      if (__all(done[0] && done[1] && done[2] && done[3])) {
-        all_done = true;
-        break;
-      }
+      if (live == 0u) break;
     }
-    buf ^= 1;
   }
 
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
@@ -144,12 +186,14 @@ __global__ __launch_bounds__(WAVE) void render_fwd_kernel(int W, int H, int grid
   uint32_t mx = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    if (inside[k]) {
-      const size_t pix = (size_t)(py0 + 8 * (k >> 1)) * W + (px0 + 8 * (k & 1));
-      out_color[pix] = Cr[k] + T[k] * bg0;
-      out_color[HW + pix] = Cg[k] + T[k] * bg1;
-      out_color[2 * HW + pix] = Cb[k] + T[k] * bg2;
-      final_T[pix] = T[k];
+    const int px = px0 + 8 * (k & 1), py = py0 + 8 * (k >> 1);
+    if (px < W && py < H) {
+      const float Tf = T[k] > 0.0f ? T[k] : Tfin[k];
+      const size_t pix = (size_t)py * W + px;
+      out_color[pix] = Cr[k] + Tf * bg0;
+      out_color[HW + pix] = Cg[k] + Tf * bg1;
+      out_color[2 * HW + pix] = Cb[k] + Tf * bg2;
+      final_T[pix] = Tf;
       n_contrib[pix] = last[k];
       mx = max(mx, last[k]);
     }
@@ -157,22 +201,44 @@ __global__ __launch_bounds__(WAVE) void render_fwd_kernel(int W, int H, int grid
 #pragma unroll
   for (int d = WAVE / 2; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, WAVE));
   if (lane == 0) tile_max[tile] = mx;
+  if (STATS && lane == 0) {
+    atomicAdd(&stats[0], (unsigned long long)(end - start));
+    atomicAdd(&stats[1], (unsigned long long)st_staged);
+    atomicAdd(&stats[2], (unsigned long long)st_visited);
+    atomicAdd(&stats[3], (unsigned long long)st_evals);
+    atomicAdd(&stats[4], (unsigned long long)st_hits);
+    atomicAdd(&stats[5], (unsigned long long)mx);
+  }
 }
 
-// ---- wave-wide sum with DPP (result valid in lane 63) ---------------------------------------
-template <int CTRL, int ROW_MASK>
+// ---- wave-wide sums ---------------------------------------------------------------------------
+template <int CTRL>
 __device__ inline float dpp_add(float v) {
-  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
   return v + __int_as_float(moved);
 }
-__device__ inline float wave_sum_lane63(float v) {
-  v = dpp_add<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
-  v = dpp_add<0x141, 0xf>(v);   // row_half_mirror
-  v = dpp_add<0x140, 0xf>(v);   // row_mirror  -> every lane holds its row's sum
-  v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
-  v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+// every lane ends with the sum over its 16-lane row
+__device__ inline float row_sum16(float v) {
+  v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);   // row_half_mirror
+  v = dpp_add<0x140>(v);   // row_mirror
   return v;
+}
+// lanes 0..31 end with x[i] + x[i+32], lanes 32..63 with y[i-32] + y[i]
+__device__ inline float fold32(float x, float y) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// rows (0,1,2,3) end with (x.r0 + x.r1, y.r0 + y.r1, x.r2 + x.r3, y.r2 + y.r3)
+__device__ inline float fold16(float x, float y) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// Wave-wide sums of four values at once: row 0 of the result holds sum(q0), row 1 sum(q2),
+// row 2 sum(q1), row 3 sum(q3) (every lane of the row).  10 VALU ops instead of 24.
+__device__ inline float wave_sum4(float q0, float q1, float q2, float q3) {
+  return row_sum16(fold16(fold32(q0, q1), fold32(q2, q3)));
 }
 
 __global__ __launch_bounds__(WAVE) void render_bwd_kernel(int W, int H, int grid_x,
@@ -186,60 +252,62 @@ __global__ __launch_bounds__(WAVE) void render_bwd_kernel(int W, int H, int grid
                                                           const float* __restrict__ dL_dpix,
                                                           GradRow* __restrict__ rows,
                                                           uint8_t* __restrict__ row_flags) {
-  __shared__ float4 sA[2][BATCH];
-  __shared__ float4 sB[2][BATCH];
-  __shared__ float sC[2][BATCH];
+  __shared__ float4 sA[BATCH];
+  __shared__ float4 sB[BATCH];
+  __shared__ float sC[BATCH];
 
   const int tile = blockIdx.x;
   const int lane = threadIdx.x;
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
   const int px0 = tile_x * TILE + (lane & 7), py0 = tile_y * TILE + (lane >> 3);
   const float tx0 = (float)(tile_x * TILE), ty0 = (float)(tile_y * TILE);
+  const float pxf0 = (float)px0, pyf0 = (float)py0;
   const size_t HW = (size_t)W * H;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-  const float half_w = 0.5f * (float)W, half_h = 0.5f * (float)H;
+  // scale factors applied once per instance after the wave reduction
+  const float sc_mx = 0.5f * (float)W / LOG2E, sc_my = 0.5f * (float)H / LOG2E;
 
-  float pxf[4], pyf[4], T[4], Tfin[4], dpr[4], dpg[4], dpb[4], bgdot[4];
-  float acc_r[4], acc_g[4], acc_b[4], last_a[4], last_r[4], last_g[4], last_b[4];
+  // per pixel: T (running transmittance in front of the current instance), Bk = sum over the
+  // instances behind of (c.dL_dpix)*alpha*T  +  T_final*(bg.dL_dpix)
+  float T[4], Bk[4], dpr[4], dpg[4], dpb[4];
   uint32_t last[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int px = px0 + 8 * (k & 1), py = py0 + 8 * (k >> 1);
-    pxf[k] = (float)px;
-    pyf[k] = (float)py;
     const bool in = px < W && py < H;
     const size_t pix = (size_t)py * W + px;
-    Tfin[k] = in ? final_T[pix] : 0.0f;
-    T[k] = Tfin[k];
+    T[k] = in ? final_T[pix] : 0.0f;
     last[k] = in ? n_contrib[pix] : 0u;
     dpr[k] = in ? dL_dpix[pix] : 0.0f;
     dpg[k] = in ? dL_dpix[HW + pix] : 0.0f;
     dpb[k] = in ? dL_dpix[2 * HW + pix] : 0.0f;
-    bgdot[k] = bg0 * dpr[k] + bg1 * dpg[k] + bg2 * dpb[k];
-    acc_r[k] = acc_g[k] = acc_b[k] = 0.0f;
-    last_a[k] = last_r[k] = last_g[k] = last_b[k] = 0.0f;
+    Bk[k] = T[k] * (bg0 * dpr[k] + bg1 * dpg[k] + bg2 * dpb[k]);
   }
 
   const uint2 range = ranges[tile];
   const uint32_t start = range.x;
-  uint32_t hi = min(range.y - range.x, tile_max[tile]);   // instances past the last contributor got no gradient
+  uint32_t hi = min(range.y - range.x, tile_max[tile]);   // instances past the last contributor get no gradient
 
   Staged st;
   st.q0 = st.q1 = st.q2 = make_float4(0.f, 0.f, 0.f, 0.f);
   st.rect_min = st.rect_wh = 0;
-  auto stage = [&](uint32_t lo, uint32_t top) {
-    if (lo + lane < top) {
-      const uint32_t id = point_list[start + lo + lane];
-      load_staged(rec, id, st);
-      const uint2 rr = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(rec + id) + 48);
-      st.rect_min = rr.x;
-      st.rect_wh = rr.y;
-    }
+  // unconditional, index-clamped staging loads (see the forward kernel): ids two rounds ahead,
+  // records one round ahead, walking the list back to front
+  auto load_id = [&](uint32_t lo, uint32_t top) { return point_list[start + min(lo + lane, top - 1)]; };
+  auto load_rec = [&](uint32_t id) {
+    load_staged<true>(rec, id, st);
+    const uint2 rr = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(rec + id) + 48);
+    st.rect_min = rr.x;
+    st.rect_wh = rr.y;
   };
   uint32_t lo = hi > BATCH ? hi - BATCH : 0u;
-  stage(lo, hi);
+  uint32_t id_next = 0;
+  if (hi > 0) {
+    load_rec(load_id(lo, hi));
+    const uint32_t lo2 = lo > BATCH ? lo - BATCH : 0u;
+    id_next = load_id(lo2, max(lo, 1u));
+  }
 
-  int buf = 0;
   while (hi > 0) {
     const bool have = lo + lane < hi;
     const uint32_t m = have ? subblock_mask(st.q0.x, st.q0.y, st.q2.y, st.q2.z, tx0, ty0) : 0u;
@@ -247,94 +315,104 @@ __global__ __launch_bounds__(WAVE) void render_bwd_kernel(int W, int H, int grid
     const uint32_t rw = st.rect_wh & 0xffffu;
     const uint32_t slot = __float_as_uint(st.q2.w) + ((uint32_t)tile_y - (st.rect_min >> 16)) * rw +
                           ((uint32_t)tile_x - (st.rect_min & 0xffffu));
-    sA[buf][lane] = st.q0;
-    sB[buf][lane] = st.q1;
-    sC[buf][lane] = st.q2.x;
+    LdsRec lr;
+    make_lds(st, lr);
+    __syncthreads();
+    sA[lane] = lr.A;
+    sB[lane] = lr.B;
+    sC[lane] = st.q2.x;
     __syncthreads();
     const uint32_t cur_lo = lo;
     hi = lo;
     lo = hi > BATCH ? hi - BATCH : 0u;
-    if (hi > 0) stage(lo, hi);   // prefetch the next (earlier) round
+    {   // prefetch: record of the next (earlier) round, ids of the one after it
+      load_rec(id_next);
+      const uint32_t lo2 = lo > BATCH ? lo - BATCH : 0u;
+      id_next = load_id(lo2, max(lo, 1u));
+    }
 
     unsigned long long nz = __ballot(m != 0u);
     while (nz) {
       const int j = 63 - __clzll((long long)nz);   // back to front
       nz &= ~(1ull << j);
       const uint32_t mj = (uint32_t)__builtin_amdgcn_readlane((int)m, j);
-      const float4 a = sA[buf][j];
-      const float4 b = sB[buf][j];
-      const float cb = sC[buf][j];
+      const float4 a = sA[j];
+      const float4 b = sB[j];
+      const float cb = sC[j];
       const uint32_t pos1 = cur_lo + (uint32_t)j + 1u;
-      float g_mx = 0.f, g_my = 0.f, g_cxx = 0.f, g_cxy = 0.f, g_cyy = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f,
-            g_b = 0.f;
+      // per-lane partial sums over the sub-blocks; un-scaled forms (constants applied after the reduction):
+      //   g_mx = sum h*(2aq dx + bq dy), g_my = sum h*(2cq dy + bq dx), g_xx = sum h dx^2, g_xy = sum h dx dy,
+      //   g_yy = sum h dy^2 with h = opacity*G*dL_dalpha;  g_op = sum G*dL_dalpha;  g_r/g/b = sum alpha*T*dL_dpix
+      float g_mx = 0.f, g_my = 0.f, g_xx = 0.f, g_xy = 0.f, g_yy = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
       bool any = false;
+      const float dx0 = a.x - pxf0, dy0 = a.y - pyf0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (mj & (1u << k)) {
-          const float dx = a.x - pxf[k], dy = a.y - pyf[k];
-          const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-          const float G = __expf(power);
+          const float dx = (k & 1) ? dx0 - 8.0f : dx0;
+          const float dy = (k >> 1) ? dy0 - 8.0f : dy0;
+          const float adx = a.z * dx;
+          const float t = fmaf(a.w, dy, adx);
+          const float cdy = b.x * dy;
+          const float p2 = fmaf(dx, t, cdy * dy);
+          const float G = __builtin_amdgcn_exp2f(p2);
           const float alpha = fminf(ALPHA_MAX, b.y * G);
-          const bool ok = pos1 <= last[k] && power <= 0.0f && alpha >= ALPHA_MIN;
+          const bool ok = (pos1 <= last[k]) && (p2 <= 0.0f) && (alpha >= ALPHA_MIN);
           if (ok) {
             any = true;
-            const float one_m = 1.0f - alpha;
-            T[k] = T[k] / one_m;
+            const float rcp = __builtin_amdgcn_rcpf(1.0f - alpha);
+            T[k] *= rcp;                                   // transmittance in front of this instance
+            const float cd = fmaf(cb, dpb[k], fmaf(b.w, dpg[k], b.z * dpr[k]));   // c . dL_dpix
             const float dch = alpha * T[k];
-            acc_r[k] = last_a[k] * last_r[k] + (1.0f - last_a[k]) * acc_r[k];
-            acc_g[k] = last_a[k] * last_g[k] + (1.0f - last_a[k]) * acc_g[k];
-            acc_b[k] = last_a[k] * last_b[k] + (1.0f - last_a[k]) * acc_b[k];
-            last_r[k] = b.z; last_g[k] = b.w; last_b[k] = cb; last_a[k] = alpha;
-            float dL_dalpha = (b.z - acc_r[k]) * dpr[k] + (b.w - acc_g[k]) * dpg[k] + (cb - acc_b[k]) * dpb[k];
-            g_r += dch * dpr[k];
-            g_g += dch * dpg[k];
-            g_b += dch * dpb[k];
-            dL_dalpha *= T[k];
-            dL_dalpha += (-Tfin[k] / one_m) * bgdot[k];
-            const float dL_dG = b.y * dL_dalpha;
-            const float gdx = G * dx, gdy = G * dy;
-            const float dG_ddelx = -gdx * a.z - gdy * a.w;
-            const float dG_ddely = -gdy * b.x - gdx * a.w;
-            g_mx += dL_dG * dG_ddelx * half_w;
-            g_my += dL_dG * dG_ddely * half_h;
-            g_cxx += -0.5f * gdx * dx * dL_dG;
-            g_cxy += -gdx * dy * dL_dG;          // true derivative (upstream keeps half and doubles later)
-            g_cyy += -0.5f * gdy * dy * dL_dG;
-            g_op += G * dL_dalpha;
+            const float dL_dalpha = fmaf(T[k], cd, -Bk[k] * rcp);
+            Bk[k] = fmaf(cd, dch, Bk[k]);
+            g_r = fmaf(dch, dpr[k], g_r);
+            g_g = fmaf(dch, dpg[k], g_g);
+            g_b = fmaf(dch, dpb[k], g_b);
+            const float gd = G * dL_dalpha;
+            g_op += gd;
+            const float h = b.y * gd;
+            const float hx = h * dx, hy = h * dy;
+            g_mx = fmaf(h, t + adx, g_mx);
+            g_my = fmaf(h, fmaf(a.w, dx, cdy + cdy), g_my);
+            g_xx = fmaf(hx, dx, g_xx);
+            g_xy = fmaf(hx, dy, g_xy);
+            g_yy = fmaf(hy, dy, g_yy);
           }
         }
       }
       if (__any(any)) {
-        g_mx = wave_sum_lane63(g_mx);
-        g_my = wave_sum_lane63(g_my);
-        g_cxx = wave_sum_lane63(g_cxx);
-        g_cxy = wave_sum_lane63(g_cxy);
-        g_cyy = wave_sum_lane63(g_cyy);
-        g_op = wave_sum_lane63(g_op);
-        g_r = wave_sum_lane63(g_r);
-        g_g = wave_sum_lane63(g_g);
-        g_b = wave_sum_lane63(g_b);
+        const float s0 = wave_sum4(g_mx, g_xx, g_my, g_xy);   // rows: mx, my, xx, xy
+        const float s1 = wave_sum4(g_yy, g_r, g_op, g_g);     // rows: yy, op, r, g
+        const float s2 = row_sum16(fold16(fold32(g_b, g_b), 0.0f));   // row 0 (and 2): b
         const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)slot, j);
-        if (lane == WAVE - 1) {
-          float4* dst = reinterpret_cast<float4*>(rows + sj);
-          dst[0] = make_float4(g_mx, g_my, g_cxx, g_cxy);
-          dst[1] = make_float4(g_cyy, g_op, g_r, g_g);
-          dst[2] = make_float4(g_b, 0.f, 0.f, 0.f);
-          row_flags[sj] = 1;
+        float* dst = reinterpret_cast<float*>(rows + sj);
+        if ((lane & 15) == 0) {
+          const int r = lane >> 4;
+          const float f0 = r == 0 ? sc_mx : (r == 1 ? sc_my : (r == 2 ? -0.5f : -1.0f));
+          dst[r] = s0 * f0;                                    // dmx, dmy, dcxx, dcxy
+          const float f1 = r == 0 ? -0.5f : 1.0f;
+          dst[4 + r] = s1 * f1;                                // dcyy, dop, dr, dg
+          if (r == 0) {
+            dst[8] = s2;
+            row_flags[sj] = 1;
+          }
         }
       }
     }
-    buf ^= 1;
   }
 }
 
-
 void launch_render_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
                        const float* bg, float* out_color, float* final_T, uint32_t* n_contrib, uint32_t* tile_max,
-                       hipStream_t s) {
+                       hipStream_t s, unsigned long long* stats) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-  hipLaunchKernelGGL(render_fwd_kernel, dim3(gx * gy), dim3(WAVE), 0, s, W, H, gx, ranges, point_list, rec, bg,
-                     out_color, final_T, n_contrib, tile_max);
+  if (stats)
+    hipLaunchKernelGGL(render_fwd_kernel<true>, dim3(gx * gy), dim3(WAVE), 0, s, W, H, gx, ranges, point_list, rec, bg,
+                       out_color, final_T, n_contrib, tile_max, stats);
+  else
+    hipLaunchKernelGGL(render_fwd_kernel<false>, dim3(gx * gy), dim3(WAVE), 0, s, W, H, gx, ranges, point_list, rec,
+                       bg, out_color, final_T, n_contrib, tile_max, stats);
 }
 void launch_render_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
                        const float* bg, const float* final_T, const uint32_t* n_contrib, const uint32_t* tile_max,

@@ -79,6 +79,7 @@ def _make_params(dev, settings: GaussianRasterizationSettings, means3D, sh, colo
     p.opacities, p.scales, p.rotations = _ptr(opacities), _ptr(scales), _ptr(rotations)
     p.cov3D_precomp = _ptr(cov3Ds_precomp)
     p.viewmatrix, p.projmatrix, p.campos, p.bg = view.data_ptr(), proj.data_ptr(), campos.data_ptr(), bg.data_ptr()
+    p.profile = _lib.active_profile_handle()
     return p, [bg, view, proj, campos]
 
 
@@ -125,6 +126,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise
 
         ctx.raster_settings = raster_settings
+        ctx.profile = params.profile     # backward runs on an autograd thread: carry the handle explicitly
         ctx.num_rendered = R
         ctx.keep = keep
         ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, geom,
@@ -146,6 +148,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         with torch.cuda.device(dev):
             params, keep = _make_params(dev, settings, means3D, sh, colors_precomp, opacities, scales, rotations,
                                         cov3Ds_precomp)
+            params.profile = ctx.profile
             stream = _stream(dev)
             new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
             g_means3D, g_means2D, g_opac = new(P, 3), new(P, 3), new(*opacities.shape)

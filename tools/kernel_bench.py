@@ -1,0 +1,30 @@
+"""Per-stage device times of the raw C-ABI forward/backward on a bench config (no Python host work in
+between): python tools/kernel_bench.py [C4] [iters]."""
+import sys
+
+import torch
+
+from mvs_gaussian_splatting_amd import _lib
+from scene_gpu import GpuScene
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C4"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+s = GpuScene(cfg)
+dL = torch.sign(torch.rand(3, s.H, s.W, device=s.dev) - 0.5) / (3 * s.H * s.W)
+for _ in range(2):
+    s.forward(); s.backward(dL)
+torch.cuda.synchronize()
+prof = _lib.StageProfile()
+s.params.profile = prof._h
+t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True); t2 = torch.cuda.Event(enable_timing=True)
+tf = tb = 0.0
+for _ in range(iters):
+    t0.record(); s.forward(); t1.record(); s.backward(dL); t2.record()
+    torch.cuda.synchronize()
+    tf += t0.elapsed_time(t1); tb += t1.elapsed_time(t2)
+res = prof.collect()
+s.params.profile = None
+print(f"{cfg}: P={s.P} R={s.R} visible={int((s.radii > 0).sum())} fwd={tf / iters:.3f} ms bwd={tb / iters:.3f} ms")
+for k, (ms, n) in res.items():
+    if n:
+        print(f"  {k:24s} {ms / n:8.4f} ms")

@@ -1,0 +1,65 @@
+"""Shared setup for the GPU tuning tools: a bench scene resident on cuda:0 plus raw C-ABI handles."""
+import ctypes as C
+import math
+
+import torch
+
+from mvs_gaussian_splatting_amd import _lib
+from mvs_gaussian_splatting_amd.rasterizer import GaussianRasterizationSettings, _make_params
+from mvs_gaussian_splatting_amd.synthetic import CONFIGS, make_scene
+
+
+class GpuScene:
+    def __init__(self, cfgname="C4", P=None, view=0):
+        self.cfg = cfg = CONFIGS[cfgname]
+        self.dev = dev = torch.device("cuda:0")
+        self.lib = _lib.load()
+        model, cam, bg, target = make_scene(cfg, P=P, view=view)
+        model.to(dev); cam.to(dev)
+        self.model, self.cam, self.bg, self.target = model, cam, bg.to(dev), target.to(dev)
+        self.W, self.H, self.P = cfg.width, cfg.height, P or cfg.P
+        self.settings = GaussianRasterizationSettings(
+            self.H, self.W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), self.bg, 1.0,
+            cam.world_view_transform, cam.full_proj_transform, cfg.sh_degree, cam.camera_center, False, False)
+        e = torch.empty(0, device=dev)
+        with torch.no_grad():
+            # keep every input alive for as long as `params` (raw pointers) is used
+            self.inputs = [model.get_xyz.contiguous(), model.get_features.contiguous(), e,
+                           model.get_opacity.contiguous(), model.get_scaling.contiguous(),
+                           model.get_rotation.contiguous(), e]
+        self.params, self.keep = _make_params(dev, self.settings, *self.inputs)
+        self.stream = torch.cuda.current_stream(dev).cuda_stream
+        lib = self.lib
+        self.geom = torch.empty(lib.gsr_geom_bytes(self.P), dtype=torch.uint8, device=dev)
+        self.img = torch.empty(lib.gsr_image_bytes(self.W, self.H), dtype=torch.uint8, device=dev)
+        self.radii = torch.zeros(self.P, dtype=torch.int32, device=dev)
+        self.color = torch.empty(3, self.H, self.W, device=dev)
+        self.R = 0
+        self.binning = None
+
+    def forward(self):
+        lib = self.lib
+        R = C.c_uint32(0)
+        _lib.check(lib.gsr_forward_preprocess(C.byref(self.params), self.geom.data_ptr(), self.radii.data_ptr(),
+                                              self.stream, C.byref(R)), "pre")
+        self.R = R.value
+        nb = lib.gsr_binning_bytes(self.R, self.W, self.H)
+        if self.binning is None or self.binning.numel() < nb:
+            self.binning = torch.empty(nb, dtype=torch.uint8, device=self.dev)
+        _lib.check(lib.gsr_forward_render(C.byref(self.params), self.geom.data_ptr(), self.binning.data_ptr(),
+                                          self.binning.numel(), self.img.data_ptr(), self.R, self.color.data_ptr(),
+                                          self.stream), "render")
+
+    def backward(self, dL_dpix):
+        lib, dev, P = self.lib, self.dev, self.P
+        if not hasattr(self, "grads"):
+            new = lambda *s: torch.empty(*s, device=dev)  # noqa: E731
+            self.g = [new(P, 3), new(P, 3), new(P, 16, 3), new(P, 1), new(P, 3), new(P, 4)]
+            self.grads = _lib.GsrGrads(self.g[0].data_ptr(), self.g[1].data_ptr(), self.g[2].data_ptr(), None,
+                                       self.g[3].data_ptr(), self.g[4].data_ptr(), self.g[5].data_ptr(), None)
+        nb = lib.gsr_backward_bytes(P, self.R)
+        if not hasattr(self, "bwd_ws") or self.bwd_ws.numel() < nb:
+            self.bwd_ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        _lib.check(lib.gsr_backward(C.byref(self.params), self.radii.data_ptr(), self.geom.data_ptr(),
+                                    self.binning.data_ptr(), self.img.data_ptr(), self.R, dL_dpix.data_ptr(),
+                                    self.bwd_ws.data_ptr(), self.bwd_ws.numel(), C.byref(self.grads), self.stream), "bwd")
