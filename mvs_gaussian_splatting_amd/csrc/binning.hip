@@ -264,6 +264,40 @@ __global__ __launch_bounds__(256) void identify_tile_ranges_kernel(uint32_t R, c
 }
 
 
+// ------------------------------------------------------------------------------------------
+// Tile processing order for the compositing kernels: longest instance list first (bucketed by a
+// monotone 8-bit code of the length), so that the waves that start late pick up the short tiles.
+// One block.  The order inside a bucket is arbitrary; no result depends on it.
+// ------------------------------------------------------------------------------------------
+__device__ inline uint32_t len_bucket(uint32_t len) {
+  if (len < 16u) return len;
+  const uint32_t e = 31u - (uint32_t)__clz((int)len);          // >= 4
+  const uint32_t b = 16u + (e - 4u) * 8u + ((len >> (e - 3u)) & 7u);
+  return b > 255u ? 255u : b;
+}
+__global__ __launch_bounds__(1024) void build_tile_order_kernel(int tiles, const uint2* __restrict__ ranges,
+                                                                uint32_t* __restrict__ order) {
+  __shared__ uint32_t cnt[256];
+  __shared__ uint32_t base[256];
+  const int tid = threadIdx.x;
+  if (tid < 256) cnt[tid] = 0;
+  __syncthreads();
+  for (int t = tid; t < tiles; t += 1024) {
+    const uint2 r = ranges[t];
+    atomicAdd(&cnt[255u - len_bucket(r.y - r.x)], 1u);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t run = 0;
+    for (int i = 0; i < 256; ++i) { base[i] = run; run += cnt[i]; }
+  }
+  __syncthreads();
+  for (int t = tid; t < tiles; t += 1024) {
+    const uint2 r = ranges[t];
+    order[atomicAdd(&base[255u - len_bucket(r.y - r.x)], 1u)] = (uint32_t)t;
+  }
+}
+
 void launch_duplicate_with_keys(int P, int grid_x, const BinInfo* bin, const uint32_t* block_offs, GeomRec* rec,
                                 uint32_t* point_offsets, uint64_t* keys, uint32_t* vals, hipStream_t s) {
   const int nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
@@ -290,6 +324,10 @@ bool launch_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uin
     uint32_t* tv = vin; vin = vout; vout = tv;
   }
   return (passes & 1) != 0;
+}
+
+void launch_build_tile_order(int tiles, const uint2* ranges, uint32_t* order, hipStream_t s) {
+  hipLaunchKernelGGL(build_tile_order_kernel, dim3(1), dim3(1024), 0, s, tiles, ranges, order);
 }
 
 void launch_identify_tile_ranges(uint32_t R, const uint64_t* keys, uint2* ranges, hipStream_t s) {

@@ -178,10 +178,12 @@ int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t b
     if (int rc = check(p, s, "identify_tile_ranges")) return rc;
     point_list = in_b ? vb : va;
   }
+  launch_build_tile_order(I.tiles, ranges, at<uint32_t>(img_ws, I.tile_order), s);
   {
     StageTimer t(p, GSR_STAGE_RENDER_FWD, s);
     launch_render_fwd(p->width, p->height, ranges, point_list, rec, p->bg, out_color, at<float>(img_ws, I.final_T),
-                      at<uint32_t>(img_ws, I.n_contrib), at<uint32_t>(img_ws, I.tile_max), s);
+                      at<uint32_t>(img_ws, I.n_contrib), at<uint32_t>(img_ws, I.tile_max),
+                      at<uint32_t>(img_ws, I.tile_order), at<uint32_t>(img_ws, I.queues), s);
   }
   return check(p, s, "render_fwd");
 }
@@ -215,7 +217,9 @@ int gsr_backward(const GsrParams* p, const int32_t* radii, const void* geom_ws, 
       StageTimer t(p, GSR_STAGE_RENDER_BWD, s);
       launch_render_bwd(p->width, p->height, at<uint2>(img_ws, I.ranges), point_list, rec, p->bg,
                         at<float>(img_ws, I.final_T), at<uint32_t>(img_ws, I.n_contrib),
-                        at<uint32_t>(img_ws, I.tile_max), dL_dout_color, rows, flags, s);
+                        at<uint32_t>(img_ws, I.tile_max), dL_dout_color, rows, flags,
+                        at<uint32_t>(img_ws, I.tile_order),
+                        const_cast<uint32_t*>(at<uint32_t>(img_ws, I.queues)) + 1, s);
     }
     if (int rc = check(p, s, "render_bwd")) return rc;
   }
@@ -275,7 +279,8 @@ int gsr_debug_render_stats(const GsrParams* p, const void* geom_ws, const void* 
   launch_render_fwd(p->width, p->height, at<uint2>(img_ws, I.ranges),
                     at<uint32_t>(bin_ws, sorted_in_b(p->width, p->height) ? B.vals_b : B.vals_a),
                     at<GeomRec>(geom_ws, L.rec), p->bg, out_color, at<float>(img_ws, I.final_T),
-                    at<uint32_t>(img_ws, I.n_contrib), at<uint32_t>(img_ws, I.tile_max), s, stats);
+                    at<uint32_t>(img_ws, I.n_contrib), at<uint32_t>(img_ws, I.tile_max),
+                    at<uint32_t>(img_ws, I.tile_order), at<uint32_t>(img_ws, I.queues), s, stats);
   return check(p, s, "render_stats");
 }
 

@@ -69,7 +69,7 @@ struct GeomLayout {
 };
 
 struct ImageLayout {
-  size_t final_T, n_contrib, ranges, tile_max, bytes;
+  size_t final_T, n_contrib, ranges, tile_max, tile_order, queues, bytes;
   int grid_x, grid_y, tiles;
   __host__ __device__ ImageLayout(int W, int H) {
     grid_x = (W + TILE - 1) / TILE;
@@ -81,6 +81,8 @@ struct ImageLayout {
     n_contrib = o; o = align_up(o + 4 * px, 256);
     ranges = o;    o = align_up(o + 8 * (size_t)tiles, 256);
     tile_max = o;  o = align_up(o + 4 * (size_t)tiles, 256);
+    tile_order = o; o = align_up(o + 4 * (size_t)tiles, 256);   // tiles, longest list first
+    queues = o;    o = align_up(o + 64, 256);                    // work-queue heads: [0] forward, [1] backward
     bytes = o;
   }
 };

@@ -20,14 +20,17 @@ bool launch_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uin
                        int end_bit, void* scratch, hipStream_t s);
 inline int sort_passes(int end_bit) { return (end_bit + RADIX_BITS - 1) / RADIX_BITS; }
 void launch_identify_tile_ranges(uint32_t R, const uint64_t* keys, uint2* ranges, hipStream_t s);
+void launch_build_tile_order(int tiles, const uint2* ranges, uint32_t* order, hipStream_t s);
 
 // render.hip
 void launch_render_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
                        const float* bg, float* out_color, float* final_T, uint32_t* n_contrib, uint32_t* tile_max,
-                       hipStream_t s, unsigned long long* stats = nullptr);
+                       const uint32_t* tile_order, uint32_t* queue, hipStream_t s,
+                       unsigned long long* stats = nullptr);
 void launch_render_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
                        const float* bg, const float* final_T, const uint32_t* n_contrib, const uint32_t* tile_max,
-                       const float* dL_dpix, GradRow* rows, uint8_t* row_flags, hipStream_t s);
+                       const float* dL_dpix, GradRow* rows, uint8_t* row_flags, const uint32_t* tile_order,
+                       uint32_t* queue, hipStream_t s);
 
 // aux.hip
 void launch_l1_loss(const float* x, const float* gt, size_t n, float scale, float* loss_sum, float* dL_dx,

@@ -14,10 +14,15 @@
 // row per (Gaussian, tile) instance -- no atomics; preprocess_bwd sums the rows per Gaussian.
 #include "gsr_common.h"
 #include "gsr_launch.h"
+#include <stdlib.h>
 
 namespace gsr {
 
 constexpr int BATCH = WAVE;   // instances staged per round
+// Tiles are independent and each is owned by one wave; four of them share a 256-lane workgroup only to
+// reach 8 waves per SIMD (a CU holds fewer single-wave workgroups than waves).  No workgroup barrier is
+// used: each wave has its own LDS slice, and LDS operations of one wave execute in order.
+constexpr int WAVES_PER_BLOCK = 4;
 constexpr float LOG2E = 1.4426950408889634f;
 
 // What one lane fetches for the instance it stages (GeomRec words 0..11 and, for the backward, 12..13).
@@ -66,42 +71,34 @@ __device__ inline void make_lds(const Staged& st, LdsRec& o) {
   o.B = make_float4((-0.5f * LOG2E) * st.q1.x, st.q1.y, st.q1.z, st.q1.w);
 }
 
-// Per-lane pixel state: T > 0 while the pixel is live; a pixel that is done (or outside the image)
-// carries T == 0 so that every later test_T = T*(1-alpha) = 0 < 1e-4 keeps it out of the blend,
-// and its final transmittance is parked in Tfin.
+// Per-lane pixel state: T > 0 while the pixel is live.  A pixel that saturates keeps its final
+// transmittance with the sign flipped (T < 0; outside the image: T = 0), so every later
+// test_T = T*(1-alpha) <= 0 < 1e-4 keeps it out of the blend without a separate flag.
 template <bool STATS>
-__global__ __launch_bounds__(WAVE) void render_fwd_kernel(int W, int H, int grid_x,
-                                                          const uint2* __restrict__ ranges,
-                                                          const uint32_t* __restrict__ point_list,
-                                                          const GeomRec* __restrict__ rec,
-                                                          const float* __restrict__ bg,
-                                                          float* __restrict__ out_color,
-                                                          float* __restrict__ final_T,
-                                                          uint32_t* __restrict__ n_contrib,
-                                                          uint32_t* __restrict__ tile_max,
-                                                          unsigned long long* __restrict__ stats) {
-  __shared__ float4 sA[BATCH];
-  __shared__ float4 sB[BATCH];
-  __shared__ float sC[BATCH];
-
-  const int tile = blockIdx.x;
-  const int lane = threadIdx.x;
+__device__ __forceinline__ void render_fwd_tile(const int tile, float4* sA, float4* sB, float* sC, int W, int H,
+                                                int grid_x, const uint2* __restrict__ ranges,
+                                                const uint32_t* __restrict__ point_list,
+                                                const GeomRec* __restrict__ rec, const float* __restrict__ bg,
+                                                float* __restrict__ out_color, float* __restrict__ final_T,
+                                                uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_max,
+                                                unsigned long long* __restrict__ stats) {
+  const int lane = threadIdx.x & (WAVE - 1);
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
   const int px0 = tile_x * TILE + (lane & 7), py0 = tile_y * TILE + (lane >> 3);
   const float tx0 = (float)(tile_x * TILE), ty0 = (float)(tile_y * TILE);
-  const float pxf0 = (float)px0, pyf0 = (float)py0;
+  float pxf0 = (float)px0, pyf0 = (float)py0;
+  asm volatile("" : "+v"(pxf0), "+v"(pyf0));   // keep them in registers (no per-visit re-conversion)
 
-  float T[4], Tfin[4], Cr[4], Cg[4], Cb[4];
+  float T[4], Cr[4], Cg[4], Cb[4];
   uint32_t last[4];
   uint32_t live = 0;   // wave-uniform: bit k set while sub-block k still has a live pixel
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const bool in = (px0 + 8 * (k & 1)) < W && (py0 + 8 * (k >> 1)) < H;
     T[k] = in ? 1.0f : 0.0f;
-    Tfin[k] = 1.0f;
     Cr[k] = Cg[k] = Cb[k] = 0.0f;
     last[k] = 0;
-    if (__any(in)) live |= 1u << k;
+    if (__builtin_amdgcn_ballot_w64(in) != 0ull) live |= 1u << k;
   }
 
   const uint2 range = ranges[tile];
@@ -127,14 +124,20 @@ __global__ __launch_bounds__(WAVE) void render_fwd_kernel(int W, int H, int grid
     const uint32_t m = have ? subblock_mask(st.q0.x, st.q0.y, st.q2.y, st.q2.z, tx0, ty0) : 0u;
     LdsRec lr;
     make_lds(st, lr);
-    __syncthreads();            // single-wave workgroup: previous round's broadcast reads are done
+    __builtin_amdgcn_wave_barrier();   // LDS ops of one wave execute in order: no hardware barrier needed
     sA[lane] = lr.A;
     sB[lane] = lr.B;
     sC[lane] = st.q2.x;
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     // prefetch the next round while this one is composited
     load_staged<false>(rec, id_next, st);
     id_next = point_list[min(pos + 2 * BATCH + lane, end - 1)];
+
+    // sub-blocks whose pixels are all parked need no further work; re-derived once per round
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (__builtin_amdgcn_ballot_w64(T[k] > 0.0f) == 0ull) live &= ~(1u << k);
+    if (live == 0u) break;
 
     unsigned long long nz = __ballot(m != 0u);
     while (nz) {
@@ -158,26 +161,20 @@ __global__ __launch_bounds__(WAVE) void render_fwd_kernel(int W, int H, int grid
           const float alpha = fminf(ALPHA_MAX, b.y * __builtin_amdgcn_exp2f(p2));
           const bool ok = (p2 <= 0.0f) && (alpha >= ALPHA_MIN);
           const float test_T = T[k] * (1.0f - alpha);
-          const bool stop = ok && (test_T < T_STOP);
-          if (STATS) { ++st_evals; if (__any(ok && T[k] > 0.0f)) ++st_hits; }
-          if (ok && !stop) {
+          const bool go = ok && !(test_T < T_STOP);
+          if (STATS) { ++st_evals; if (__ballot(ok && T[k] > 0.0f) != 0ull) ++st_hits; }
+          // ok && !go: the pixel saturates here (or is already parked): park it with the sign flipped
+          const float parked = ok ? -fabsf(T[k]) : T[k];
+          if (go) {
             const float w = alpha * T[k];
             Cr[k] = fmaf(b.z, w, Cr[k]);
             Cg[k] = fmaf(b.w, w, Cg[k]);
             Cb[k] = fmaf(cb, w, Cb[k]);
-            T[k] = test_T;
             last[k] = pos1;
           }
-          if (__any(stop)) {           // rare: some pixel saturates here (or is already parked)
-            if (stop && T[k] > 0.0f) {
-              Tfin[k] = T[k];
-              T[k] = 0.0f;
-            }
-            if (!__any(T[k] > 0.0f)) live &= ~(1u << k);
-          }
+          T[k] = go ? test_T : parked;
         }
       }
-      if (live == 0u) break;
     }
   }
 
@@ -188,7 +185,7 @@ __global__ __launch_bounds__(WAVE) void render_fwd_kernel(int W, int H, int grid
   for (int k = 0; k < 4; ++k) {
     const int px = px0 + 8 * (k & 1), py = py0 + 8 * (k >> 1);
     if (px < W && py < H) {
-      const float Tf = T[k] > 0.0f ? T[k] : Tfin[k];
+      const float Tf = fabsf(T[k]);
       const size_t pix = (size_t)py * W + px;
       out_color[pix] = Cr[k] + Tf * bg0;
       out_color[HW + pix] = Cg[k] + Tf * bg1;
@@ -209,6 +206,31 @@ __global__ __launch_bounds__(WAVE) void render_fwd_kernel(int W, int H, int grid
     atomicAdd(&stats[4], (unsigned long long)st_hits);
     atomicAdd(&stats[5], (unsigned long long)mx);
   }
+}
+
+// One wave per tile; blockIdx walks the tiles longest-list-first (tile_order), so the hardware
+// dispatcher hands the short tiles to the slots that free up last.
+template <bool STATS>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) void render_fwd_kernel(int W, int H, int grid_x, int num_tiles,
+                                                          const uint32_t* __restrict__ tile_order,
+                                                          const uint2* __restrict__ ranges,
+                                                          const uint32_t* __restrict__ point_list,
+                                                          const GeomRec* __restrict__ rec,
+                                                          const float* __restrict__ bg,
+                                                          float* __restrict__ out_color,
+                                                          float* __restrict__ final_T,
+                                                          uint32_t* __restrict__ n_contrib,
+                                                          uint32_t* __restrict__ tile_max,
+                                                          unsigned long long* __restrict__ stats) {
+  __shared__ float4 sA[WAVES_PER_BLOCK][BATCH];
+  __shared__ float4 sB[WAVES_PER_BLOCK][BATCH];
+  __shared__ float sC[WAVES_PER_BLOCK][BATCH];
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+  const int slot = blockIdx.x * WAVES_PER_BLOCK + wid;
+  if (slot >= num_tiles) return;
+  const int tile = __builtin_amdgcn_readfirstlane((int)tile_order[slot]);
+  render_fwd_tile<STATS>(tile, sA[wid], sB[wid], sC[wid], W, H, grid_x, ranges, point_list, rec, bg, out_color, final_T, n_contrib,
+                         tile_max, stats);
 }
 
 // ---- wave-wide sums ---------------------------------------------------------------------------
@@ -241,27 +263,21 @@ __device__ inline float wave_sum4(float q0, float q1, float q2, float q3) {
   return row_sum16(fold16(fold32(q0, q1), fold32(q2, q3)));
 }
 
-__global__ __launch_bounds__(WAVE) void render_bwd_kernel(int W, int H, int grid_x,
-                                                          const uint2* __restrict__ ranges,
-                                                          const uint32_t* __restrict__ point_list,
-                                                          const GeomRec* __restrict__ rec,
-                                                          const float* __restrict__ bg,
-                                                          const float* __restrict__ final_T,
-                                                          const uint32_t* __restrict__ n_contrib,
-                                                          const uint32_t* __restrict__ tile_max,
-                                                          const float* __restrict__ dL_dpix,
-                                                          GradRow* __restrict__ rows,
-                                                          uint8_t* __restrict__ row_flags) {
-  __shared__ float4 sA[BATCH];
-  __shared__ float4 sB[BATCH];
-  __shared__ float sC[BATCH];
-
-  const int tile = blockIdx.x;
-  const int lane = threadIdx.x;
+__device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, float4* sB, float* sC, int W, int H,
+                                                int grid_x, const uint2* __restrict__ ranges,
+                                                const uint32_t* __restrict__ point_list,
+                                                const GeomRec* __restrict__ rec, const float* __restrict__ bg,
+                                                const float* __restrict__ final_T,
+                                                const uint32_t* __restrict__ n_contrib,
+                                                const uint32_t* __restrict__ tile_max,
+                                                const float* __restrict__ dL_dpix, GradRow* __restrict__ rows,
+                                                uint8_t* __restrict__ row_flags) {
+  const int lane = threadIdx.x & (WAVE - 1);
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
   const int px0 = tile_x * TILE + (lane & 7), py0 = tile_y * TILE + (lane >> 3);
   const float tx0 = (float)(tile_x * TILE), ty0 = (float)(tile_y * TILE);
-  const float pxf0 = (float)px0, pyf0 = (float)py0;
+  float pxf0 = (float)px0, pyf0 = (float)py0;
+  asm volatile("" : "+v"(pxf0), "+v"(pyf0));
   const size_t HW = (size_t)W * H;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
   // scale factors applied once per instance after the wave reduction
@@ -317,11 +333,11 @@ __global__ __launch_bounds__(WAVE) void render_bwd_kernel(int W, int H, int grid
                           ((uint32_t)tile_x - (st.rect_min & 0xffffu));
     LdsRec lr;
     make_lds(st, lr);
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     sA[lane] = lr.A;
     sB[lane] = lr.B;
     sC[lane] = st.q2.x;
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     const uint32_t cur_lo = lo;
     hi = lo;
     lo = hi > BATCH ? hi - BATCH : 0u;
@@ -381,7 +397,7 @@ __global__ __launch_bounds__(WAVE) void render_bwd_kernel(int W, int H, int grid
           }
         }
       }
-      if (__any(any)) {
+      if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
         const float s0 = wave_sum4(g_mx, g_xx, g_my, g_xy);   // rows: mx, my, xx, xy
         const float s1 = wave_sum4(g_yy, g_r, g_op, g_g);     // rows: yy, op, r, g
         const float s2 = row_sum16(fold16(fold32(g_b, g_b), 0.0f));   // row 0 (and 2): b
@@ -403,23 +419,51 @@ __global__ __launch_bounds__(WAVE) void render_bwd_kernel(int W, int H, int grid
   }
 }
 
+__global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) void render_bwd_kernel(int W, int H, int grid_x, int num_tiles,
+                                                          const uint32_t* __restrict__ tile_order,
+                                                          const uint2* __restrict__ ranges,
+                                                          const uint32_t* __restrict__ point_list,
+                                                          const GeomRec* __restrict__ rec,
+                                                          const float* __restrict__ bg,
+                                                          const float* __restrict__ final_T,
+                                                          const uint32_t* __restrict__ n_contrib,
+                                                          const uint32_t* __restrict__ tile_max,
+                                                          const float* __restrict__ dL_dpix,
+                                                          GradRow* __restrict__ rows,
+                                                          uint8_t* __restrict__ row_flags) {
+  __shared__ float4 sA[WAVES_PER_BLOCK][BATCH];
+  __shared__ float4 sB[WAVES_PER_BLOCK][BATCH];
+  __shared__ float sC[WAVES_PER_BLOCK][BATCH];
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+  const int slot = blockIdx.x * WAVES_PER_BLOCK + wid;
+  if (slot >= num_tiles) return;
+  const int tile = __builtin_amdgcn_readfirstlane((int)tile_order[slot]);
+  render_bwd_tile(tile, sA[wid], sB[wid], sC[wid], W, H, grid_x, ranges, point_list, rec, bg, final_T, n_contrib, tile_max, dL_dpix,
+                  rows, row_flags);
+}
+
 void launch_render_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
                        const float* bg, float* out_color, float* final_T, uint32_t* n_contrib, uint32_t* tile_max,
-                       hipStream_t s, unsigned long long* stats) {
+                       const uint32_t* tile_order, uint32_t* queue, hipStream_t s, unsigned long long* stats) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  (void)queue;
+  const int nblk = (gx * gy + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
   if (stats)
-    hipLaunchKernelGGL(render_fwd_kernel<true>, dim3(gx * gy), dim3(WAVE), 0, s, W, H, gx, ranges, point_list, rec, bg,
-                       out_color, final_T, n_contrib, tile_max, stats);
+    hipLaunchKernelGGL(render_fwd_kernel<true>, dim3(nblk), dim3(WAVES_PER_BLOCK * WAVE), 0, s, W, H, gx, gx * gy, tile_order, ranges,
+                       point_list, rec, bg, out_color, final_T, n_contrib, tile_max, stats);
   else
-    hipLaunchKernelGGL(render_fwd_kernel<false>, dim3(gx * gy), dim3(WAVE), 0, s, W, H, gx, ranges, point_list, rec,
-                       bg, out_color, final_T, n_contrib, tile_max, stats);
+    hipLaunchKernelGGL(render_fwd_kernel<false>, dim3(nblk), dim3(WAVES_PER_BLOCK * WAVE), 0, s, W, H, gx, gx * gy, tile_order, ranges,
+                       point_list, rec, bg, out_color, final_T, n_contrib, tile_max, stats);
 }
 void launch_render_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
                        const float* bg, const float* final_T, const uint32_t* n_contrib, const uint32_t* tile_max,
-                       const float* dL_dpix, GradRow* rows, uint8_t* row_flags, hipStream_t s) {
+                       const float* dL_dpix, GradRow* rows, uint8_t* row_flags, const uint32_t* tile_order,
+                       uint32_t* queue, hipStream_t s) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-  hipLaunchKernelGGL(render_bwd_kernel, dim3(gx * gy), dim3(WAVE), 0, s, W, H, gx, ranges, point_list, rec, bg,
-                     final_T, n_contrib, tile_max, dL_dpix, rows, row_flags);
+  (void)queue;
+  const int nblk = (gx * gy + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  hipLaunchKernelGGL(render_bwd_kernel, dim3(nblk), dim3(WAVES_PER_BLOCK * WAVE), 0, s, W, H, gx, gx * gy, tile_order, ranges, point_list, rec,
+                     bg, final_T, n_contrib, tile_max, dL_dpix, rows, row_flags);
 }
 
 }  // namespace gsr
