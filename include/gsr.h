@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 1
+#define GSR_ABI_VERSION 2
 
 enum {
   GSR_OK = 0,
@@ -66,7 +66,17 @@ typedef struct GsrParams {
   const float* campos;         /* device [3] */
   const float* bg;             /* device [3] */
   void* profile;               /* NULL, or a handle from gsr_profile_create(): HIP-event stage timers */
+  /* Fused-input extension (removes the caller's torch.cat / exp / normalize / sigmoid of
+   * scene/gaussian_model.py:151-183 and their autograd): */
+  const float* shs_rest;       /* NULL, or device [P,M-1,3] (16-byte aligned): then `shs` is [P,1,3] (f_dc) */
+  int32_t act_flags;           /* GSR_ACT_*: inputs are RAW parameters, the activation (and its gradient) is applied here */
 } GsrParams;
+
+enum {
+  GSR_ACT_SCALE_EXP = 1,       /* scales    = exp(raw)              scene/gaussian_model.py:34,151-153 */
+  GSR_ACT_ROT_NORMALIZE = 2,   /* rotations = raw / max(|raw|,1e-12) scene/gaussian_model.py:42,167-169 */
+  GSR_ACT_OPACITY_SIGMOID = 4  /* opacity   = sigmoid(raw)          scene/gaussian_model.py:39,181-183 */
+};
 
 /* Gradient outputs of the backward.  Replaces the tuple returned by the reference-side
  * `_C.rasterize_gaussians_backward(...)`.  Every buffer is written in full by the call
@@ -82,6 +92,7 @@ typedef struct GsrGrads {
   float* dL_dscales;    /* device [P,3] */
   float* dL_drotations; /* device [P,4] */
   float* dL_dcov3D;     /* device [P,6] */
+  float* dL_dshs_rest;  /* device [P,M-1,3]; required with shs_rest (dL_dshs is then [P,1,3]) */
 } GsrGrads;
 
 /* ---- introspection ------------------------------------------------------------------ */

@@ -3,7 +3,8 @@
 
     from mvs_gaussian_splatting_amd import GaussianRasterizationSettings, GaussianRasterizer, render
 """
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians  # noqa: F401
+from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians,  # noqa: F401
+                         rasterize_gaussians_fused)
 from .renderer import render  # noqa: F401
 from .losses import l1_loss, add_densification_stats  # noqa: F401
 

@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class GsrParams(C.Structure):
@@ -25,6 +25,7 @@ class GsrParams(C.Structure):
         ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
         ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
         ("campos", C.c_void_p), ("bg", C.c_void_p), ("profile", C.c_void_p),
+        ("shs_rest", C.c_void_p), ("act_flags", C.c_int32),
     ]
 
 
@@ -32,8 +33,10 @@ class GsrGrads(C.Structure):
     _fields_ = [
         ("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
         ("dL_dcolors", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
-        ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p),
+        ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p), ("dL_dshs_rest", C.c_void_p),
     ]
+
+ACT_SCALE_EXP, ACT_ROT_NORMALIZE, ACT_OPACITY_SIGMOID = 1, 2, 4
 
 
 # name -> (restype, argtypes); every symbol include/gsr.h declares

@@ -57,8 +57,17 @@ int validate(const GsrParams* p) {
     if (p->D < 0 || p->D > 3) return fail(GSR_E_BADARG, "sh degree must be 0..3");
     if (p->M < (p->D + 1) * (p->D + 1)) return fail(GSR_E_BADARG, "M smaller than (D+1)^2");
     if (!p->campos) return fail(GSR_E_BADARG, "campos required with shs");
-    if (((uintptr_t)p->shs & 15u) != 0 && p->M == 16) return fail(GSR_E_ALIGN, "shs must be 16-byte aligned");
+    if (((uintptr_t)p->shs & 15u) != 0 && p->M == 16 && !p->shs_rest)
+      return fail(GSR_E_ALIGN, "shs must be 16-byte aligned");
+    if (p->shs_rest) {
+      if (p->M != 16) return fail(GSR_E_BADARG, "split SH inputs (shs_rest) require M == 16");
+      if (((uintptr_t)p->shs_rest & 15u) != 0) return fail(GSR_E_ALIGN, "shs_rest must be 16-byte aligned");
+    }
+  } else if (p->shs_rest) {
+    return fail(GSR_E_BADARG, "shs_rest given without shs");
   }
+  if ((p->act_flags & (GSR_ACT_SCALE_EXP | GSR_ACT_ROT_NORMALIZE)) && !p->scales)
+    return fail(GSR_E_BADARG, "scale / rotation activations need the scales + rotations inputs");
   if (p->rotations && ((uintptr_t)p->rotations & 15u) != 0) return fail(GSR_E_ALIGN, "rotations must be 16-byte aligned");
   return 0;
 }
@@ -198,6 +207,10 @@ int gsr_backward(const GsrParams* p, const int32_t* radii, const void* geom_ws, 
   if (!grads->dL_dmeans3D || !grads->dL_dmeans2D || !grads->dL_dopacities)
     return fail(GSR_E_BADARG, "dL_dmeans3D / dL_dmeans2D / dL_dopacities must be non-NULL");
   if (p->shs && !grads->dL_dshs) return fail(GSR_E_BADARG, "dL_dshs required with shs");
+  if (p->shs_rest && !grads->dL_dshs_rest) return fail(GSR_E_BADARG, "dL_dshs_rest required with shs_rest");
+  if (p->shs_rest && ((uintptr_t)grads->dL_dshs_rest & 15u) != 0) return fail(GSR_E_ALIGN, "dL_dshs_rest must be 16-byte aligned");
+  if (p->shs && !p->shs_rest && p->M == 16 && ((uintptr_t)grads->dL_dshs & 15u) != 0)
+    return fail(GSR_E_ALIGN, "dL_dshs must be 16-byte aligned");
   if (p->colors_precomp && !grads->dL_dcolors) return fail(GSR_E_BADARG, "dL_dcolors required with colors_precomp");
   const BwdLayout Wl(p->P, R);
   if (bwd_ws_bytes < Wl.bytes) return fail(GSR_E_CAPACITY, "backward workspace too small");

@@ -115,27 +115,96 @@ __device__ inline void eval_sh(int deg, LoadSH sh, float x, float y, float z, fl
   }
 }
 
+// ---- fused input activations: the raw parameters of scene/gaussian_model.py:151-183 -------
+struct Activated {
+  float sc[3];      // activated scales
+  float4 q;         // activated (normalised) quaternion
+  float qn;         // norm used for the normalisation (1 when not normalising)
+  float op;         // activated opacity
+};
+__device__ inline void load_scale_rot(const GsrParams& p, int idx, Activated& a) {
+  a.sc[0] = p.scales[3 * (size_t)idx];
+  a.sc[1] = p.scales[3 * (size_t)idx + 1];
+  a.sc[2] = p.scales[3 * (size_t)idx + 2];
+  if (p.act_flags & GSR_ACT_SCALE_EXP) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a.sc[k] = expf(a.sc[k]);
+  }
+  a.q = reinterpret_cast<const float4*>(p.rotations)[idx];
+  a.qn = 1.0f;
+  if (p.act_flags & GSR_ACT_ROT_NORMALIZE) {
+    a.qn = fmaxf(sqrtf(a.q.x * a.q.x + a.q.y * a.q.y + a.q.z * a.q.z + a.q.w * a.q.w), 1e-12f);
+    a.q.x = a.q.x / a.qn; a.q.y = a.q.y / a.qn; a.q.z = a.q.z / a.qn; a.q.w = a.q.w / a.qn;
+  }
+}
+__device__ inline float load_opacity(const GsrParams& p, int idx) {
+  const float o = p.opacities[idx];
+  return (p.act_flags & GSR_ACT_OPACITY_SIGMOID) ? 1.0f / (1.0f + expf(-o)) : o;
+}
+
+// Split SH inputs: f_rest is [P,15,3] (180-byte rows, not 16-byte aligned per row).  A wave's 64 rows are
+// 11520 contiguous bytes: they are moved with 16-byte accesses into / out of an LDS image with the natural
+// row stride 45 (odd: conflict-free), and each lane then works on its own row.
+constexpr int REST_ROW = 45;
+__device__ inline void wave_load_rows45(const float* __restrict__ base, int first, int rows_valid, float* st,
+                                        int lane) {
+  const float* __restrict__ src = base + (size_t)first * REST_ROW;
+  const int nfl = rows_valid * REST_ROW;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const int f = (i * WAVE + lane) * 4;
+    if (f + 3 < nfl) {
+      const float4 v = *reinterpret_cast<const float4*>(src + f);
+      st[f] = v.x; st[f + 1] = v.y; st[f + 2] = v.z; st[f + 3] = v.w;
+    } else {
+      for (int e = 0; e < 4; ++e)
+        if (f + e < nfl) st[f + e] = src[f + e];
+    }
+  }
+}
+__device__ inline void wave_store_rows45(float* __restrict__ base, int first, int rows_valid, const float* st,
+                                         int lane) {
+  float* __restrict__ dst = base + (size_t)first * REST_ROW;
+  const int nfl = rows_valid * REST_ROW;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const int f = (i * WAVE + lane) * 4;
+    if (f + 3 < nfl) {
+      *reinterpret_cast<float4*>(dst + f) = make_float4(st[f], st[f + 1], st[f + 2], st[f + 3]);
+    } else {
+      for (int e = 0; e < 4; ++e)
+        if (f + e < nfl) dst[f + e] = st[f + e];
+    }
+  }
+}
+
 __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, GeomRec* __restrict__ rec,
                                                                    BinInfo* __restrict__ bin,
                                                                    uint32_t* __restrict__ block_sums,
                                                                    int32_t* __restrict__ radii) {
   __shared__ uint32_t wave_sums[PRE_BLOCK / WAVE];
   const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
   const int W = p.width, H = p.height;
   const int grid_x = (W + TILE - 1) / TILE, grid_y = (H + TILE - 1) / TILE;
   uint32_t tiles = 0;
+  int32_t radius = 0;
+  BinInfo bi{0u, 0u, 0.0f, 0u};
+  GeomRec g;
+  bool vis = false;
+  float px = 0.f, py = 0.f, pz = 0.f;
+  Proj pr;
+  pr.a = pr.c = 1.0f;
 
+  // ---- geometry: cull, project, cov3D -> cov2D -> conic, radius, tile rect -----------------------
   if (idx < p.P) {
     Mat4 V, Mx;
     load_mat(p.viewmatrix, V);
     load_mat(p.projmatrix, Mx);
-    const float px = p.means3D[3 * (size_t)idx + 0], py = p.means3D[3 * (size_t)idx + 1],
-                pz = p.means3D[3 * (size_t)idx + 2];
+    px = p.means3D[3 * (size_t)idx + 0]; py = p.means3D[3 * (size_t)idx + 1]; pz = p.means3D[3 * (size_t)idx + 2];
     const float vx = V.m[0] * px + V.m[4] * py + V.m[8] * pz + V.m[12];
     const float vy = V.m[1] * px + V.m[5] * py + V.m[9] * pz + V.m[13];
     const float vz = V.m[2] * px + V.m[6] * py + V.m[10] * pz + V.m[14];
-    int32_t radius = 0;
-    BinInfo bi{0u, 0u, 0.0f, 0u};
     if (vz > NEAR_Z) {
       const float hx = Mx.m[0] * px + Mx.m[4] * py + Mx.m[8] * pz + Mx.m[12];
       const float hy = Mx.m[1] * px + Mx.m[5] * py + Mx.m[9] * pz + Mx.m[13];
@@ -148,17 +217,15 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
 #pragma unroll
         for (int k = 0; k < 6; ++k) cov[k] = p.cov3D_precomp[6 * (size_t)idx + k];
       } else {
-        const float4 q = reinterpret_cast<const float4*>(p.rotations)[idx];
-        cov3d_from_scale_rot(p.scales[3 * (size_t)idx], p.scales[3 * (size_t)idx + 1], p.scales[3 * (size_t)idx + 2],
-                             p.scale_modifier, q.x, q.y, q.z, q.w, cov);
+        Activated act;
+        load_scale_rot(p, idx, act);
+        cov3d_from_scale_rot(act.sc[0], act.sc[1], act.sc[2], p.scale_modifier, act.q.x, act.q.y, act.q.z, act.q.w, cov);
       }
       const float fx = (float)W / (2.0f * p.tan_fovx), fy = (float)H / (2.0f * p.tan_fovy);
-      Proj pr;
       project_cov(V, vx, vy, vz, cov, fx, fy, FOV_GUARD * p.tan_fovx, FOV_GUARD * p.tan_fovy, pr);
       const float det = pr.a * pr.c - pr.b * pr.b;
       if (det != 0.0f) {
         const float det_inv = 1.0f / det;
-        const float cxx = pr.c * det_inv, cxy = -pr.b * det_inv, cyy = pr.a * det_inv;
         const float mid = 0.5f * (pr.a + pr.c);
         const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
         const float lam = fmaxf(mid + sq, mid - sq);
@@ -174,64 +241,86 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
           const int y1 = (int)fminf(gyf, fmaxf(0.0f, truncf((my + rad + (float)(TILE - 1)) / (float)TILE)));
           const int area = (x1 - x0) * (y1 - y0);
           if (area > 0) {
-            float rgb[3];
-            uint32_t flags = 0;
-            if (p.colors_precomp) {
-              rgb[0] = p.colors_precomp[3 * (size_t)idx];
-              rgb[1] = p.colors_precomp[3 * (size_t)idx + 1];
-              rgb[2] = p.colors_precomp[3 * (size_t)idx + 2];
-            } else {
-              const float dx = px - p.campos[0], dy = py - p.campos[1], dz = pz - p.campos[2];
-              const float ln = sqrtf(dx * dx + dy * dy + dz * dz);
-              const float ux = dx / ln, uy = dy / ln, uz = dz / ln;
-              const float* __restrict__ s = p.shs + (size_t)idx * p.M * 3;
-              if (p.M == 16) {
-                float4 v[12];
-                const float4* s4 = reinterpret_cast<const float4*>(s);
-#pragma unroll
-                for (int k = 0; k < 12; ++k) v[k] = s4[k];
-                const float* f = reinterpret_cast<const float*>(v);
-                eval_sh(p.D, [&](int k, int ch) { return f[3 * k + ch]; }, ux, uy, uz, rgb);
-              } else {
-                eval_sh(p.D, [&](int k, int ch) { return s[3 * k + ch]; }, ux, uy, uz, rgb);
-              }
-#pragma unroll
-              for (int ch = 0; ch < 3; ++ch) {
-                rgb[ch] = rgb[ch] + 0.5f;
-                if (rgb[ch] < 0.0f) flags |= 1u << ch;
-                rgb[ch] = fmaxf(rgb[ch], 0.0f);
-              }
-            }
-            const float op = p.opacities[idx];
-            // conservative half-extent of the region where alpha = op*exp(power) can reach 1/255
-            float ext_x = -1.0f, ext_y = -1.0f;
-            if (op >= ALPHA_MIN) {
-              const float t = 2.0f * logf(op * 255.0f) * 1.0001f + 1e-4f;
-              ext_x = sqrtf(t * pr.a) * 1.0001f + 0.01f;
-              ext_y = sqrtf(t * pr.c) * 1.0001f + 0.01f;
-            }
+            vis = true;
             radius = (int32_t)rad;
             tiles = (uint32_t)area;
-            GeomRec g;
-            g.x = mx; g.y = my; g.cxx = cxx; g.cxy = cxy;
-            g.cyy = cyy; g.opacity = op; g.r = rgb[0]; g.g = rgb[1];
-            g.b = rgb[2]; g.ext_x = ext_x; g.ext_y = ext_y; g.offs_excl = 0;
+            g.x = mx; g.y = my;
+            g.cxx = pr.c * det_inv; g.cxy = -pr.b * det_inv; g.cyy = pr.a * det_inv;
+            g.offs_excl = 0;
             g.rect_min = (uint32_t)x0 | ((uint32_t)y0 << 16);
             g.rect_wh = (uint32_t)(x1 - x0) | ((uint32_t)(y1 - y0) << 16);
-            g.depth = vz; g.flags = flags;
-            rec[idx] = g;
+            g.depth = vz;
             bi.rect_min = g.rect_min; bi.rect_wh = g.rect_wh; bi.depth = vz; bi.tiles = tiles;
           }
         }
       }
     }
+  }
+
+  // ---- colour ------------------------------------------------------------------------------------
+  const bool split = p.shs_rest != nullptr;
+  if (vis) {
+    float rgb[3];
+    uint32_t flags = 0;
+    if (p.colors_precomp) {
+      rgb[0] = p.colors_precomp[3 * (size_t)idx];
+      rgb[1] = p.colors_precomp[3 * (size_t)idx + 1];
+      rgb[2] = p.colors_precomp[3 * (size_t)idx + 2];
+    } else {
+      const float dx = px - p.campos[0], dy = py - p.campos[1], dz = pz - p.campos[2];
+      const float ln = sqrtf(dx * dx + dy * dy + dz * dz);
+      const float ux = dx / ln, uy = dy / ln, uz = dz / ln;
+      if (split) {
+        // f_rest rows are 180 bytes (4-byte aligned): the compiler still emits 16-byte loads (unaligned
+        // access mode), the same access shape as the unsplit [P,16,3] row
+        const float* __restrict__ dc = p.shs + 3 * (size_t)idx;
+        const float* __restrict__ rr = p.shs_rest + (size_t)idx * REST_ROW;
+        float row[REST_ROW];
+        if (p.D > 0) {
+#pragma unroll
+          for (int i = 0; i < REST_ROW; ++i) row[i] = rr[i];
+        }
+        eval_sh(p.D, [&](int k, int ch) { return k == 0 ? dc[ch] : row[3 * (k - 1) + ch]; }, ux, uy, uz, rgb);
+      } else {
+        const float* __restrict__ s = p.shs + (size_t)idx * p.M * 3;
+        if (p.M == 16) {
+          float4 v[12];
+          const float4* s4 = reinterpret_cast<const float4*>(s);
+#pragma unroll
+          for (int k = 0; k < 12; ++k) v[k] = s4[k];
+          const float* f = reinterpret_cast<const float*>(v);
+          eval_sh(p.D, [&](int k, int ch) { return f[3 * k + ch]; }, ux, uy, uz, rgb);
+        } else {
+          eval_sh(p.D, [&](int k, int ch) { return s[3 * k + ch]; }, ux, uy, uz, rgb);
+        }
+      }
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        rgb[ch] = rgb[ch] + 0.5f;
+        if (rgb[ch] < 0.0f) flags |= 1u << ch;
+        rgb[ch] = fmaxf(rgb[ch], 0.0f);
+      }
+    }
+    const float op = load_opacity(p, idx);
+    // conservative half-extent of the region where alpha = op*exp(power) can reach 1/255
+    float ext_x = -1.0f, ext_y = -1.0f;
+    if (op >= ALPHA_MIN) {
+      const float t = 2.0f * logf(op * 255.0f) * 1.0001f + 1e-4f;
+      ext_x = sqrtf(t * pr.a) * 1.0001f + 0.01f;
+      ext_y = sqrtf(t * pr.c) * 1.0001f + 0.01f;
+    }
+    g.opacity = op; g.r = rgb[0]; g.g = rgb[1]; g.b = rgb[2];
+    g.ext_x = ext_x; g.ext_y = ext_y; g.flags = flags;
+    rec[idx] = g;
+  }
+  if (idx < p.P) {
     radii[idx] = radius;
     bin[idx] = bi;
   }
 
   // block total of tiles_touched -> first level of the hierarchical scan (§8 a5)
   const uint32_t ws = wave_reduce_add_u32(tiles);
-  if ((threadIdx.x & (WAVE - 1)) == 0) wave_sums[threadIdx.x / WAVE] = ws;
+  if (lane == 0) wave_sums[wid] = ws;
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t s = 0;
@@ -280,16 +369,39 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(GsrParams p, 
                                                                    const GradRow* __restrict__ rows,
                                                                    const uint8_t* __restrict__ row_flags,
                                                                    GsrGrads g) {
+  // dL_dsh of 64 Gaussians is 12 KB of contiguous memory: each wave stages its rows in LDS (row stride 49
+  // floats: conflict-free) and streams them out with 16-byte stores, instead of 48 lane-strided dword stores.
+  constexpr int SH_ROW = 49;
+  __shared__ float sh_stage[PRE_BLOCK / WAVE][WAVE * SH_ROW];
   const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
-  if (idx >= p.P) return;
+  const bool valid = idx < p.P;
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
   const int M = p.M;
+  const bool split = p.shs_rest != nullptr;
+  const bool sh_lds = p.shs != nullptr && M == 16 && g.dL_dshs != nullptr;
+  float* my_row = &sh_stage[wid][lane * SH_ROW];
   float dmean[3] = {0.f, 0.f, 0.f};
   float dm2x = 0.f, dm2y = 0.f, dop = 0.f;
   float dcol[3] = {0.f, 0.f, 0.f};
   float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float dscale[3] = {0.f, 0.f, 0.f};
   float drot[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool vis = radii[idx] > 0;
+  const bool vis = valid && radii[idx] > 0;
+  const int wave_first = blockIdx.x * PRE_BLOCK + wid * WAVE;
+  const int rows_valid = min(WAVE, p.P - wave_first);
+  if (split) {
+    // dL/df_rest rows are staged in LDS (row stride 45) and streamed out with 16-byte stores
+    float* st = sh_stage[wid];
+    my_row = st + lane * REST_ROW;
+    if (!vis) {
+#pragma unroll
+      for (int k = 0; k < REST_ROW; ++k) my_row[k] = 0.0f;
+      if (valid) { g.dL_dshs[3 * (size_t)idx] = 0.f; g.dL_dshs[3 * (size_t)idx + 1] = 0.f; g.dL_dshs[3 * (size_t)idx + 2] = 0.f; }
+    }
+  } else if (sh_lds && !vis) {
+#pragma unroll
+    for (int k = 0; k < 48; ++k) my_row[k] = 0.0f;
+  }
 
   if (vis) {
     const GeomRec r = rec[idx];
@@ -317,12 +429,15 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(GsrParams p, 
     float cov[6];
     float4 q4 = make_float4(1.f, 0.f, 0.f, 0.f);
     float sc[3] = {0.f, 0.f, 0.f};
+    Activated act;
+    act.qn = 1.0f;
     if (p.cov3D_precomp) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) cov[k] = p.cov3D_precomp[6 * (size_t)idx + k];
     } else {
-      q4 = reinterpret_cast<const float4*>(p.rotations)[idx];
-      sc[0] = p.scales[3 * (size_t)idx]; sc[1] = p.scales[3 * (size_t)idx + 1]; sc[2] = p.scales[3 * (size_t)idx + 2];
+      load_scale_rot(p, idx, act);
+      q4 = act.q;
+      sc[0] = act.sc[0]; sc[1] = act.sc[1]; sc[2] = act.sc[2];
       cov3d_from_scale_rot(sc[0], sc[1], sc[2], p.scale_modifier, q4.x, q4.y, q4.z, q4.w, cov);
     }
     const float fx = (float)p.width / (2.0f * p.tan_fovx), fy = (float)p.height / (2.0f * p.tan_fovy);
@@ -414,36 +529,53 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(GsrParams p, 
       float* __restrict__ ds = g.dL_dshs + (size_t)idx * M * 3;
       const int deg = p.D;
       float dRx[3] = {0.f, 0.f, 0.f}, dRy[3] = {0.f, 0.f, 0.f}, dRz[3] = {0.f, 0.f, 0.f};
+      float4 sv4[12];
+      if (M == 16 && !split) {
+        const float4* s4 = reinterpret_cast<const float4*>(s);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) sv4[k] = s4[k];
+      } else if (split && deg > 0) {
+        const float* __restrict__ rr = p.shs_rest + (size_t)idx * REST_ROW;
+        float* f = reinterpret_cast<float*>(sv4);
+#pragma unroll
+        for (int i = 0; i < REST_ROW; ++i) f[3 + i] = rr[i];     // f[3k+ch], k >= 1
+      }
+      const float* sreg = reinterpret_cast<const float*>(sv4);
       auto emit = [&](int k, float basis) {
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) ds[3 * k + ch] = basis * dc[ch];
+        for (int ch = 0; ch < 3; ++ch) {
+          const float v = basis * dc[ch];
+          if (split) {
+            if (k == 0) g.dL_dshs[3 * (size_t)idx + ch] = v;
+            else my_row[3 * (k - 1) + ch] = v;
+          } else if (sh_lds) {
+            my_row[3 * k + ch] = v;
+          } else {
+            ds[3 * k + ch] = v;
+          }
+        }
       };
       auto dirg = [&](int k, float bx, float by, float bz) {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-          const float c = s[3 * k + ch];
+          const float c = (M == 16) ? sreg[3 * k + ch] : s[3 * k + ch];
           dRx[ch] += bx * c; dRy[ch] += by * c; dRz[ch] += bz * c;
         }
       };
       emit(0, SH_C0);
       if (deg > 0) {
-        emit(1, -SH_C1 * y); emit(2, SH_C1 * z); emit(3, -SH_C1 * x);
         dirg(1, 0.f, -SH_C1, 0.f); dirg(2, 0.f, 0.f, SH_C1); dirg(3, -SH_C1, 0.f, 0.f);
+        emit(1, -SH_C1 * y); emit(2, SH_C1 * z); emit(3, -SH_C1 * x);
         if (deg > 1) {
           const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-          emit(4, SH_C2_0 * xy); emit(5, SH_C2_1 * yz); emit(6, SH_C2_2 * (2.0f * zz - xx - yy));
-          emit(7, SH_C2_3 * xz); emit(8, SH_C2_4 * (xx - yy));
           dirg(4, SH_C2_0 * y, SH_C2_0 * x, 0.f);
           dirg(5, 0.f, SH_C2_1 * z, SH_C2_1 * y);
           dirg(6, SH_C2_2 * -2.0f * x, SH_C2_2 * -2.0f * y, SH_C2_2 * 4.0f * z);
           dirg(7, SH_C2_3 * z, 0.f, SH_C2_3 * x);
           dirg(8, SH_C2_4 * 2.0f * x, SH_C2_4 * -2.0f * y, 0.f);
+          emit(4, SH_C2_0 * xy); emit(5, SH_C2_1 * yz); emit(6, SH_C2_2 * (2.0f * zz - xx - yy));
+          emit(7, SH_C2_3 * xz); emit(8, SH_C2_4 * (xx - yy));
           if (deg > 2) {
-            emit(9, SH_C3_0 * y * (3.0f * xx - yy)); emit(10, SH_C3_1 * xy * z);
-            emit(11, SH_C3_2 * y * (4.0f * zz - xx - yy));
-            emit(12, SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy));
-            emit(13, SH_C3_4 * x * (4.0f * zz - xx - yy)); emit(14, SH_C3_5 * z * (xx - yy));
-            emit(15, SH_C3_6 * x * (xx - 3.0f * yy));
             dirg(9, SH_C3_0 * 6.0f * xy, SH_C3_0 * (3.0f * xx - 3.0f * yy), 0.f);
             dirg(10, SH_C3_1 * yz, SH_C3_1 * xz, SH_C3_1 * xy);
             dirg(11, SH_C3_2 * -2.0f * xy, SH_C3_2 * (4.0f * zz - xx - 3.0f * yy), SH_C3_2 * 8.0f * yz);
@@ -451,6 +583,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(GsrParams p, 
             dirg(13, SH_C3_4 * (4.0f * zz - 3.0f * xx - yy), SH_C3_4 * -2.0f * xy, SH_C3_4 * 8.0f * xz);
             dirg(14, SH_C3_5 * 2.0f * xz, SH_C3_5 * -2.0f * yz, SH_C3_5 * (xx - yy));
             dirg(15, SH_C3_6 * (3.0f * xx - 3.0f * yy), SH_C3_6 * -6.0f * xy, 0.f);
+            emit(9, SH_C3_0 * y * (3.0f * xx - yy)); emit(10, SH_C3_1 * xy * z);
+            emit(11, SH_C3_2 * y * (4.0f * zz - xx - yy));
+            emit(12, SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy));
+            emit(13, SH_C3_4 * x * (4.0f * zz - xx - yy)); emit(14, SH_C3_5 * z * (xx - yy));
+            emit(15, SH_C3_6 * x * (xx - 3.0f * yy));
           }
         }
       }
@@ -506,11 +643,45 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(GsrParams p, 
                 4.0f * qy * (dR[0][0] + dR[2][2]);
       drot[3] = 2.0f * (qr * (dR[1][0] - dR[0][1]) + qx * (dR[0][2] + dR[2][0]) + qy * (dR[1][2] + dR[2][1])) -
                 4.0f * qz * (dR[0][0] + dR[1][1]);
+      // chain through the fused activations back to the raw parameters
+      if (p.act_flags & GSR_ACT_SCALE_EXP) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dscale[k] *= sc[k];
+      }
+      if (p.act_flags & GSR_ACT_ROT_NORMALIZE) {
+        const float dot = qr * drot[0] + qx * drot[1] + qy * drot[2] + qz * drot[3];
+        drot[0] = (drot[0] - qr * dot) / act.qn;
+        drot[1] = (drot[1] - qx * dot) / act.qn;
+        drot[2] = (drot[2] - qy * dot) / act.qn;
+        drot[3] = (drot[3] - qz * dot) / act.qn;
+      }
     }
-  } else if (p.shs && g.dL_dshs) {
+    if (p.act_flags & GSR_ACT_OPACITY_SIGMOID) dop *= r.opacity * (1.0f - r.opacity);
+  } else if (valid && p.shs && g.dL_dshs && !sh_lds) {
     float* __restrict__ ds = g.dL_dshs + (size_t)idx * M * 3;
     for (int k = 0; k < M * 3; ++k) ds[k] = 0.0f;
   }
+
+  if (split) {
+    __builtin_amdgcn_wave_barrier();
+    wave_store_rows45(g.dL_dshs_rest, wave_first, rows_valid, sh_stage[wid], lane);
+  } else if (sh_lds) {
+    // the wave's 64 rows = 3072 contiguous floats of dL_dsh; LDS ops of one wave execute in order
+    __builtin_amdgcn_wave_barrier();
+    const int first = wave_first;
+    float* __restrict__ out = g.dL_dshs + (size_t)first * 48;
+    const float* __restrict__ st = sh_stage[wid];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int flat = i * (WAVE * 4) + lane * 4;
+      const int row = flat / 48, c = flat - row * 48;
+      if (row < rows_valid) {
+        const float* q = st + row * SH_ROW + c;
+        *reinterpret_cast<float4*>(out + flat) = make_float4(q[0], q[1], q[2], q[3]);
+      }
+    }
+  }
+  if (!valid) return;
 
   // ---- write every output row in full (no caller zero-fill needed) ---------------------------
 #pragma unroll

@@ -59,7 +59,7 @@ def _stream(dev: torch.device) -> int:
 
 
 def _make_params(dev, settings: GaussianRasterizationSettings, means3D, sh, colors_precomp, opacities, scales,
-                 rotations, cov3Ds_precomp):
+                 rotations, cov3Ds_precomp, sh_rest=None, act_flags: int = 0):
     """Returns (GsrParams, keepalive list)."""
     bg = _f32c(settings.bg, "bg", dev)
     view = _f32c(settings.viewmatrix, "viewmatrix", dev)
@@ -69,6 +69,8 @@ def _make_params(dev, settings: GaussianRasterizationSettings, means3D, sh, colo
         raise ValueError("bg/campos must have 3 elements and viewmatrix/projmatrix 16")
     P = int(means3D.shape[0])
     M = int(sh.shape[1]) if sh.numel() else 0
+    if sh_rest is not None:
+        M = 1 + int(sh_rest.shape[1])
     p = _lib.GsrParams()
     p.P, p.M, p.D = P, M, int(settings.sh_degree)
     p.width, p.height = int(settings.image_width), int(settings.image_height)
@@ -80,6 +82,8 @@ def _make_params(dev, settings: GaussianRasterizationSettings, means3D, sh, colo
     p.cov3D_precomp = _ptr(cov3Ds_precomp)
     p.viewmatrix, p.projmatrix, p.campos, p.bg = view.data_ptr(), proj.data_ptr(), campos.data_ptr(), bg.data_ptr()
     p.profile = _lib.active_profile_handle()
+    p.shs_rest = _ptr(sh_rest)
+    p.act_flags = int(act_flags)
     return p, [bg, view, proj, campos]
 
 
@@ -158,7 +162,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_rot = new(P, 4) if rotations.numel() else None
             g_cov = new(P, 6) if cov3Ds_precomp.numel() else None
             grads = _lib.GsrGrads(_ptr(g_means3D), _ptr(g_means2D), _ptr(g_sh), _ptr(g_col), _ptr(g_opac),
-                                  _ptr(g_scales), _ptr(g_rot), _ptr(g_cov))
+                                  _ptr(g_scales), _ptr(g_rot), _ptr(g_cov), None)
             nbytes = lib.gsr_backward_bytes(P, R)
             bwd_ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             try:
@@ -173,6 +177,89 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise
         del keep
         return g_means3D, g_means2D, g_sh, g_col, g_opac, g_scales, g_rot, g_cov, None
+
+
+class _RasterizeGaussiansFused(torch.autograd.Function):
+    """Same operator fed with the RAW parameters of ``scene/gaussian_model.py`` (``_features_dc``,
+    ``_features_rest``, ``_opacity``, ``_scaling``, ``_rotation``): the ``cat`` / ``sigmoid`` / ``exp`` /
+    ``normalize`` of the getters at ``scene/gaussian_model.py:151-183`` and their autograd run inside the
+    preprocess kernels.  Gradients are w.r.t. the raw parameters."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations,
+                raster_settings: GaussianRasterizationSettings):
+        lib = _lib.load()
+        dev = _require_gpu(means3D)
+        P = int(means3D.shape[0])
+        means3D = _f32c(means3D, "means3D", dev)
+        f_dc = _f32c(f_dc, "f_dc", dev)
+        f_rest = _f32c(f_rest, "f_rest", dev, align16=True)
+        raw_opacity = _f32c(raw_opacity, "opacity", dev)
+        raw_scales = _f32c(raw_scales, "scaling", dev)
+        raw_rotations = _f32c(raw_rotations, "rotation", dev, align16=True)
+        if f_dc.shape[0] != P or f_dc.numel() != 3 * P or f_rest.shape[0] != P or f_rest.shape[1] != 15:
+            raise ValueError("fused inputs need f_dc [P,1,3] and f_rest [P,15,3]")
+        H, W = int(raster_settings.image_height), int(raster_settings.image_width)
+        empty = torch.empty(0, dtype=torch.float32, device=dev)
+        flags = _lib.ACT_SCALE_EXP | _lib.ACT_ROT_NORMALIZE | _lib.ACT_OPACITY_SIGMOID
+        with torch.cuda.device(dev):
+            params, keep = _make_params(dev, raster_settings, means3D, f_dc, empty, raw_opacity, raw_scales,
+                                        raw_rotations, empty, sh_rest=f_rest, act_flags=flags)
+            stream = _stream(dev)
+            geom = torch.empty(lib.gsr_geom_bytes(P), dtype=torch.uint8, device=dev)
+            img = torch.empty(lib.gsr_image_bytes(W, H), dtype=torch.uint8, device=dev)
+            radii = torch.zeros(P, dtype=torch.int32, device=dev)
+            color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+            num_rendered = C.c_uint32(0)
+            _lib.check(lib.gsr_forward_preprocess(C.byref(params), geom.data_ptr(), _ptr(radii), stream,
+                                                  C.byref(num_rendered)), "gsr_forward_preprocess")
+            R = int(num_rendered.value)
+            nbytes = lib.gsr_binning_bytes(R, W, H)
+            binning = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.gsr_forward_render(C.byref(params), geom.data_ptr(), binning.data_ptr(), nbytes,
+                                              img.data_ptr(), R, color.data_ptr(), stream), "gsr_forward_render")
+        ctx.raster_settings = raster_settings
+        ctx.profile = params.profile
+        ctx.num_rendered = R
+        ctx.act_flags = flags
+        ctx.keep = keep
+        ctx.save_for_backward(means3D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations, radii, geom, binning, img)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii):
+        lib = _lib.load()
+        means3D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations, radii, geom, binning, img = ctx.saved_tensors
+        settings = ctx.raster_settings
+        dev = means3D.device
+        P = int(means3D.shape[0])
+        R = ctx.num_rendered
+        grad_out_color = _f32c(grad_out_color, "grad_out_color", dev, align16=True)
+        empty = torch.empty(0, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            params, keep = _make_params(dev, settings, means3D, f_dc, empty, raw_opacity, raw_scales, raw_rotations,
+                                        empty, sh_rest=f_rest, act_flags=ctx.act_flags)
+            params.profile = ctx.profile
+            stream = _stream(dev)
+            new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
+            g_means3D, g_means2D = new(P, 3), new(P, 3)
+            g_dc, g_rest = new(*f_dc.shape), new(*f_rest.shape)
+            g_opac, g_scales, g_rot = new(*raw_opacity.shape), new(P, 3), new(P, 4)
+            grads = _lib.GsrGrads(_ptr(g_means3D), _ptr(g_means2D), _ptr(g_dc), None, _ptr(g_opac), _ptr(g_scales),
+                                  _ptr(g_rot), None, _ptr(g_rest))
+            nbytes = lib.gsr_backward_bytes(P, R)
+            bwd_ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.gsr_backward(C.byref(params), _ptr(radii), geom.data_ptr(), binning.data_ptr(),
+                                        img.data_ptr(), R, grad_out_color.data_ptr(), bwd_ws.data_ptr(), nbytes,
+                                        C.byref(grads), stream), "gsr_backward")
+        del keep
+        return g_means3D, g_means2D, g_dc, g_rest, g_opac, g_scales, g_rot, None
+
+
+def rasterize_gaussians_fused(means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations, raster_settings):
+    return _RasterizeGaussiansFused.apply(means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations,
+                                          raster_settings)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -205,3 +292,8 @@ class GaussianRasterizer(nn.Module):
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                    cov3D_precomp, raster_settings)
+
+    def forward_fused(self, means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations):
+        """Raw-parameter entry: see :class:`_RasterizeGaussiansFused`."""
+        return rasterize_gaussians_fused(means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations,
+                                         self.raster_settings)

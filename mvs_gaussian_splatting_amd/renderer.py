@@ -13,6 +13,24 @@ from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 from .sh import eval_sh
 
 
+def _can_fuse(pc, pipe, override_color) -> bool:
+    """The raw-parameter fast path applies when the model is the reference's parameterisation
+    (``scene/gaussian_model.py:27-42``: exp / sigmoid / normalize activations, degree-3 SH storage split
+    into ``_features_dc`` / ``_features_rest``) and no Python-side fallback was requested."""
+    if override_color is not None or getattr(pipe, "convert_SHs_python", False) or \
+            getattr(pipe, "compute_cov3D_python", False) or not getattr(pipe, "fuse_activations", True):
+        return False
+    need = ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")
+    if not all(hasattr(pc, k) for k in need):
+        return False
+    if getattr(pc, "scaling_activation", None) is not torch.exp or \
+            getattr(pc, "opacity_activation", None) is not torch.sigmoid or \
+            getattr(pc, "rotation_activation", None) is not torch.nn.functional.normalize:
+        return False
+    fr = pc._features_rest
+    return fr.dim() == 3 and fr.shape[1] == 15 and pc._features_dc.shape[1] == 1 and pc._xyz.is_cuda
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier: float = 1.0,
            override_color=None, **_fork_kwargs):
     """Render the scene; ``bg_color`` must be on the GPU.  Returns the reference's result dict
@@ -40,6 +58,13 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier:
         debug=bool(getattr(pipe, "debug", False)),
     )
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+
+    if _can_fuse(pc, pipe, override_color):
+        # same result as the getter path below, without materialising cat(f_dc, f_rest), exp, normalize, sigmoid
+        rendered_image, radii = rasterizer.forward_fused(xyz, screenspace_points, pc._features_dc, pc._features_rest,
+                                                         pc._opacity, pc._scaling, pc._rotation)
+        return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+                "radii": radii, "selected_pts_mask": None}
 
     scales = rotations = cov3D_precomp = None
     if getattr(pipe, "compute_cov3D_python", False):

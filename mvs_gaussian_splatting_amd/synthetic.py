@@ -114,6 +114,10 @@ class SyntheticGaussianModel:
         ctr = torch.tensor(centre, dtype=torch.float32)
         self.max_sh_degree = sh_degree
         self.active_sh_degree = sh_degree
+        # the activation attributes the reference model carries (scene/gaussian_model.py:34-42)
+        self.scaling_activation = torch.exp
+        self.opacity_activation = torch.sigmoid
+        self.rotation_activation = torch.nn.functional.normalize
         self._xyz = (torch.rand(P, 3, generator=g) * 2 - 1) * ext + ctr
         self._scaling = log_scale_mean + 0.4 * torch.randn(P, 3, generator=g)
         self._rotation = torch.randn(P, 4, generator=g)
@@ -176,6 +180,7 @@ class PipelineParams:
     convert_SHs_python = False
     compute_cov3D_python = False
     debug = False
+    fuse_activations = True     # this build's extension: feed raw parameters to the operator when possible
 
 
 def make_scene(cfg: SceneConfig, seed: int = 0, device="cpu", P: Optional[int] = None, view: int = 0,
