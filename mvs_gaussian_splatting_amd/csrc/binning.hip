@@ -82,23 +82,31 @@ __global__ __launch_bounds__(PRE_BLOCK) void duplicate_with_keys_kernel(int P, i
 // Item order inside a block tile: wave w owns [w*1024, w*1024+1024); item i of lane l is
 // element i*64 + l of that range, so (i, l) lexicographic == memory order (stability).
 // ------------------------------------------------------------------------------------------
-__device__ inline uint32_t digit_of(uint64_t k, int shift) { return (uint32_t)(k >> shift) & (RADIX - 1); }
+__device__ inline uint32_t digit_of(uint64_t k, int shift, uint32_t mask) { return (uint32_t)(k >> shift) & mask; }
 
 __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint64_t* __restrict__ keys, uint32_t n,
-                                                                  int shift, uint32_t nblocks,
+                                                                  int shift, uint32_t mask, uint32_t nblocks,
                                                                   uint32_t* __restrict__ hist) {
   __shared__ uint32_t h[RADIX];
   const int tid = threadIdx.x;
-  h[tid] = 0;
+#pragma unroll
+  for (int d = tid; d < RADIX; d += SORT_THREADS) h[d] = 0;
   __syncthreads();
   const uint32_t base = blockIdx.x * SORT_TILE;
-#pragma unroll 4
+  uint64_t kk[SORT_ITEMS];
+#pragma unroll
+  for (int i = 0; i < SORT_ITEMS; ++i) {       // all loads in flight before the first LDS atomic
+    const uint32_t g = base + i * SORT_THREADS + tid;
+    kk[i] = g < n ? keys[g] : 0ull;
+  }
+#pragma unroll
   for (int i = 0; i < SORT_ITEMS; ++i) {
     const uint32_t g = base + i * SORT_THREADS + tid;
-    if (g < n) atomicAdd(&h[digit_of(keys[g], shift)], 1u);
+    if (g < n) atomicAdd(&h[digit_of(kk[i], shift, mask)], 1u);
   }
   __syncthreads();
-  hist[(size_t)tid * nblocks + blockIdx.x] = h[tid];
+#pragma unroll
+  for (int d = tid; d < RADIX; d += SORT_THREADS) hist[(size_t)d * nblocks + blockIdx.x] = h[d];
 }
 
 // one block per digit row
@@ -131,11 +139,11 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(uint32_t* __restrict
 
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t* __restrict__ keys_out,
-    uint32_t* __restrict__ vals_out, uint32_t n, int shift, uint32_t nblocks, const uint32_t* __restrict__ hist,
+    uint32_t* __restrict__ vals_out, uint32_t n, int shift, uint32_t mask, uint32_t nblocks,
+    const uint32_t* __restrict__ hist,
     const uint32_t* __restrict__ totals) {
   constexpr int NW = SORT_THREADS / WAVE;
-  __shared__ uint64_t xkeys[SORT_TILE];
-  __shared__ uint32_t xvals[SORT_TILE];
+  __shared__ uint64_t xbuf[SORT_TILE];        // exchange buffer: keys first, then reused for the values
   __shared__ uint32_t wave_hist[NW][RADIX];   // per-wave digit counts, then exclusive wave prefixes
   __shared__ uint32_t digit_start[RADIX];     // first local slot of every digit
   __shared__ uint32_t global_base[RADIX];     // global position of the block's first item of the digit
@@ -146,7 +154,9 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
   const uint32_t wbase = base + wid * (WAVE * SORT_ITEMS);
 
 #pragma unroll
-  for (int w = 0; w < NW; ++w) wave_hist[w][tid] = 0;
+  for (int w = 0; w < NW; ++w)
+#pragma unroll
+    for (int d = tid; d < RADIX; d += SORT_THREADS) wave_hist[w][d] = 0;
   __syncthreads();
 
   uint64_t k[SORT_ITEMS];
@@ -155,18 +165,20 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
 #pragma unroll
   for (int i = 0; i < SORT_ITEMS; ++i) {
     const uint32_t g = wbase + i * WAVE + lane;
-    const bool ok = g < n;
-    k[i] = ok ? keys_in[g] : ~0ull;
-    v[i] = ok ? vals_in[g] : 0u;
+    const uint32_t gc = min(g, n - 1u);       // unconditional, index-clamped loads: all in flight together
+    k[i] = keys_in[gc];
+    v[i] = vals_in[gc];
   }
+  // Stable rank of every item among the wave's items with the same digit: match masks by ballot, then the
+  // wave's digit counter is read by every matching lane and bumped by the lowest one (LDS operations of a
+  // wave execute in order, so all peers read before the leader writes).
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
   for (int i = 0; i < SORT_ITEMS; ++i) {
     const uint32_t g = wbase + i * WAVE + lane;
     const bool ok = g < n;
-    const uint32_t d = digit_of(k[i], shift);
-    // lanes of this wave holding the same digit (padding lanes never match real ones)
-    unsigned long long peers = __ballot(ok);
+    const uint32_t d = digit_of(k[i], shift, mask);
+    unsigned long long peers = __ballot(ok);   // padding lanes never match real ones
     if (!ok) peers = ~peers;
 #pragma unroll
     for (int b = 0; b < RADIX_BITS; ++b) {
@@ -178,33 +190,44 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
     uint32_t old = 0;
     if (ok) {
-      old = wave_hist[wid][d];                       // every peer reads before the leader writes:
-      if (before == 0) wave_hist[wid][d] = old + cnt;  // LDS ops of one wave execute in order
+      old = wave_hist[wid][d];
+      if (before == 0) wave_hist[wid][d] = old + cnt;
     }
     rank[i] = old + before;
   }
   __syncthreads();
 
-  // digit totals over the 4 waves -> exclusive wave prefixes + block-wide exclusive scan
+  // digit totals over the 4 waves -> exclusive wave prefixes + block-wide exclusive scan.
+  // Thread t owns the BPT adjacent digits t*BPT .. t*BPT+BPT-1.
   {
-    uint32_t run = 0;
+    constexpr int BPT = RADIX / SORT_THREADS;
+    uint32_t dsum[BPT], tot[BPT];
+    uint32_t mine = 0, tmine = 0;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const uint32_t c = wave_hist[w][tid];
-      wave_hist[w][tid] = run;
-      run += c;
+    for (int e = 0; e < BPT; ++e) {
+      const int d = tid * BPT + e;
+      uint32_t run = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const uint32_t c = wave_hist[w][d];
+        wave_hist[w][d] = run;
+        run += c;
+      }
+      dsum[e] = run;
+      mine += run;
+      tot[e] = totals[d];
+      tmine += tot[e];
     }
-    const uint32_t inc = wave_incl_scan_u32(run);
+    const uint32_t inc = wave_incl_scan_u32(mine);
     if (lane == WAVE - 1) scan_tmp[wid] = inc;
     __syncthreads();
     uint32_t woff = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w)
       if (w < wid) woff += scan_tmp[w];
-    const uint32_t excl = woff + inc - run;
-    digit_start[tid] = excl;
+    uint32_t excl = woff + inc - mine;
     // global base: all smaller digits everywhere + this digit in earlier blocks
-    uint32_t t_inc = wave_incl_scan_u32(totals[tid]);
+    const uint32_t t_inc = wave_incl_scan_u32(tmine);
     __syncthreads();
     if (lane == WAVE - 1) scan_tmp[wid] = t_inc;
     __syncthreads();
@@ -212,33 +235,53 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
 #pragma unroll
     for (int w = 0; w < NW; ++w)
       if (w < wid) toff += scan_tmp[w];
-    global_base[tid] = toff + t_inc - totals[tid] + hist[(size_t)tid * nblocks + blockIdx.x];
+    uint32_t texcl = toff + t_inc - tmine;
+#pragma unroll
+    for (int e = 0; e < BPT; ++e) {
+      const int d = tid * BPT + e;
+      digit_start[d] = excl;
+      global_base[d] = texcl + hist[(size_t)d * nblocks + blockIdx.x];
+      excl += dsum[e];
+      texcl += tot[e];
+    }
   }
   __syncthreads();
 
-  // exchange: local slot = digit_start + (items of the digit in earlier waves) + rank in wave
+  // exchange through LDS so that every digit's run leaves the block contiguously; keys and values take
+  // turns in the same buffer.  local slot = digit_start + (items of the digit in earlier waves) + rank in wave
 #pragma unroll
-  for (int i = 0; i < SORT_ITEMS; ++i) {
+  for (int i = 0; i < SORT_ITEMS; ++i) {   // the rank becomes the local slot in place
     const uint32_t g = wbase + i * WAVE + lane;
-    if (g < n) {
-      const uint32_t d = digit_of(k[i], shift);
-      const uint32_t slot = digit_start[d] + wave_hist[wid][d] + rank[i];
-      xkeys[slot] = k[i];
-      xvals[slot] = v[i];
-    }
+    const uint32_t d = digit_of(k[i], shift, mask);
+    rank[i] = digit_start[d] + wave_hist[wid][d] + rank[i];
+    if (g < n) xbuf[rank[i]] = k[i];
   }
   __syncthreads();
   const uint32_t count = min((uint32_t)SORT_TILE, n - base);
+  uint32_t dst[SORT_ITEMS];
 #pragma unroll
   for (int i = 0; i < SORT_ITEMS; ++i) {
     const uint32_t s = i * SORT_THREADS + tid;
+    dst[i] = 0;
     if (s < count) {
-      const uint64_t kk = xkeys[s];
-      const uint32_t d = digit_of(kk, shift);
-      const uint32_t dst = global_base[d] + (s - digit_start[d]);
-      keys_out[dst] = kk;
-      vals_out[dst] = xvals[s];
+      const uint64_t kk = xbuf[s];
+      const uint32_t d = digit_of(kk, shift, mask);
+      dst[i] = global_base[d] + (s - digit_start[d]);
+      keys_out[dst[i]] = kk;
     }
+  }
+  __syncthreads();
+  uint32_t* xv = reinterpret_cast<uint32_t*>(xbuf);
+#pragma unroll
+  for (int i = 0; i < SORT_ITEMS; ++i) {
+    const uint32_t g = wbase + i * WAVE + lane;
+    if (g < n) xv[rank[i]] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < SORT_ITEMS; ++i) {
+    const uint32_t s = i * SORT_THREADS + tid;
+    if (s < count) vals_out[dst[i]] = xv[s];
   }
 }
 
@@ -316,10 +359,12 @@ bool launch_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uin
   uint64_t* kin = keys_a; uint32_t* vin = vals_a; uint64_t* kout = keys_b; uint32_t* vout = vals_b;
   for (int pass = 0; pass < passes; ++pass) {
     const int shift = pass * RADIX_BITS;
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(L.nblocks), dim3(SORT_THREADS), 0, s, kin, n, shift, L.nblocks, hist);
+    const int nbits = end_bit - shift < RADIX_BITS ? end_bit - shift : RADIX_BITS;   // ignore bits >= end_bit
+    const uint32_t mask = (1u << nbits) - 1u;
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(L.nblocks), dim3(SORT_THREADS), 0, s, kin, n, shift, mask, L.nblocks, hist);
     hipLaunchKernelGGL(radix_rowscan_kernel, dim3(RADIX), dim3(256), 0, s, hist, L.nblocks, totals);
     hipLaunchKernelGGL(radix_scatter_kernel, dim3(L.nblocks), dim3(SORT_THREADS), 0, s, kin, vin, kout, vout, n, shift,
-                       L.nblocks, hist, totals);
+                       mask, L.nblocks, hist, totals);
     uint64_t* tk = kin; kin = kout; kout = tk;
     uint32_t* tv = vin; vin = vout; vout = tv;
   }

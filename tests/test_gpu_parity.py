@@ -237,3 +237,32 @@ def test_fused_raw_parameter_path_matches_unfused_and_oracle(gpu_device):
         g = out[True][2][k].to(torch.float64)
         err = float((g - r).abs().max()) / max(float(r.abs().max()), 1e-30)
         assert err <= tol, (k, err, n_fragile)
+
+
+@pytest.mark.parametrize("n,end_bit", [(1, 45), (63, 45), (4097, 45), (1_000_003, 45), (300_000, 64), (50_000, 17)])
+def test_sort_pairs_u64_matches_numpy_stable_argsort(gpu_device, n, end_bit):
+    """stable LSD radix sort of (u64 key, u32 value) on bits [0, end_bit): bit-exact against
+    numpy.argsort(kind='stable') of the masked keys (values carry the original index, so stability is checked)."""
+    import ctypes as C
+    from mvs_gaussian_splatting_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(n)
+    keys = rng.integers(0, 2 ** 63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
+    if n > 1000:
+        keys[: n // 4] = keys[0]                      # long runs of duplicates
+    mask = np.uint64((1 << end_bit) - 1) if end_bit < 64 else np.uint64(2 ** 64 - 1)
+    order = np.argsort(keys & mask, kind="stable")
+    dev = gpu_device
+    k = torch.from_numpy(keys.view(np.int64)).to(dev)
+    v = torch.arange(n, dtype=torch.int32, device=dev)
+    kt, vt = torch.empty_like(k), torch.empty_like(v)
+    scratch = torch.empty(lib.gsr_sort_scratch_bytes(n), dtype=torch.uint8, device=dev)
+    in_tmp = C.c_int32(0)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gsr_sort_pairs_u64(k.data_ptr(), v.data_ptr(), kt.data_ptr(), vt.data_ptr(), n, end_bit,
+                                          scratch.data_ptr(), torch.cuda.current_stream(dev).cuda_stream,
+                                          C.byref(in_tmp)), "sort")
+        torch.cuda.synchronize()
+    ko, vo = (kt, vt) if in_tmp.value else (k, v)
+    assert np.array_equal(vo.cpu().numpy().astype(np.int64), order)
+    assert np.array_equal(ko.cpu().numpy().view(np.uint64), keys[order])
