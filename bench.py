@@ -43,12 +43,26 @@ def algorithmic_bytes(P, M, R, W, H, passes):
     }
 
 
-def cpu_baseline(cfg, seed, budget_tiles=96):
+def usable_cores():
+    """Host cores this process may really use: affinity mask, cgroup CPU quota, and a cap of 16 (a 1-GPU box's
+    share); os.cpu_count() on a big host oversubscribes the OpenMP pool by an order of magnitude."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(cfg, seed, budget_tiles=1024):
     """Pure-PyTorch CPU oracle timed on the host cores over a bounded sample of the same workload: full
     preprocess + full binning, compositing forward (+ L1 + backward) on every k-th tile, extrapolated."""
     from oracle import RasterSettings, preprocess_ref, bin_ref, render_tiles_ref
     from mvs_gaussian_splatting_amd.synthetic import make_scene
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(usable_cores())
+    print(f"[bench] cpu_baseline: oracle on {torch.get_num_threads()} threads ...", file=sys.stderr, flush=True)
     model, cam, bg, target = make_scene(cfg, seed=seed)
     st = RasterSettings(cam.image_height, cam.image_width, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0,
                         cam.world_view_transform, cam.full_proj_transform, cfg.sh_degree, cam.camera_center)
@@ -57,8 +71,10 @@ def cpu_baseline(cfg, seed, budget_tiles=96):
         pre = preprocess_ref(model.get_xyz, model.get_opacity, st, shs=model.get_features,
                              scales=model.get_scaling, rotations=model.get_rotation)
         t1 = time.perf_counter()
+        print(f"[bench] cpu_baseline: preprocess {t1 - t0:.1f}s", file=sys.stderr, flush=True)
         keys, plist, ranges = bin_ref(pre)
         t2 = time.perf_counter()
+        print(f"[bench] cpu_baseline: binning {t2 - t1:.1f}s", file=sys.stderr, flush=True)
         gx, gy = pre["grid"]
         n_tiles = gx * gy
         stride = max(1, int(math.ceil(n_tiles / budget_tiles)))
@@ -86,6 +102,8 @@ def main():
     ap.add_argument("--config", default="C4", choices=["C2", "C3", "C4"])
     ap.add_argument("--gaussians", type=int, default=None, help="override P (debug only; marks the line invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true",
+                    help="feed the operator through the reference getters (cat/exp/normalize/sigmoid in torch)")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
@@ -101,11 +119,17 @@ def main():
             raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; GSR_BENCH_SHARE_GPU=1 (rehearsal on a 1-GPU box, gloo backend) lets ranks share cuda:0
+    share = os.environ.get("GSR_BENCH_SHARE_GPU") == "1"
+    dev = torch.device("cuda", 0 if share else local_rank)
     torch.cuda.set_device(dev)
+    backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     cfg = CONFIGS[args.config]
     P = args.gaussians or cfg.P
@@ -117,12 +141,16 @@ def main():
     for p in model.parameters():
         p.requires_grad_(True)
     pipe = PipelineParams()
+    pipe.fuse_activations = not args.unfused
     W, H = cfg.width, cfg.height
     M = (cfg.sh_degree + 1) ** 2
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if backend == "nccl":
+                dist.barrier(device_ids=[dev.index])
+            else:
+                dist.barrier()
         torch.cuda.synchronize(dev)
 
     def fwd_step():
@@ -198,7 +226,9 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(args.config, {}).get(dominant)
+                # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, gfx950-corrected) of this
+                # same command, recorded by tools/traffic_from_pmc.py; null when no measurement is on file
+                traffic = json.load(open(tfile)).get(args.config, {}).get(dominant, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         roof = {"kernel": dominant, "bound": "hbm", "achieved": table[dominant]["achieved_GBs"], "peak": HBM_PEAK_GBS,
@@ -217,6 +247,8 @@ def main():
             "config": {"workload": f"{args.config}: {P} Gaussians, SH degree {cfg.sh_degree}, {W}x{H}, one view per GPU; "
                                    "value = forward-only steps, ms_per_step = render+L1+backward+densify-stats steps",
                        "gaussians": P, "visible": visible, "instances_R": R, "views_per_step": world,
+                       "inputs": ("raw parameters (split SH, exp/normalize/sigmoid inside the kernels)"
+                                  if pipe.fuse_activations else "reference getters (torch cat/exp/normalize/sigmoid)"),
                        "valid": args.gaussians is None},
             "roofline": roof,
             "roofline_by_kernel": table,
@@ -230,7 +262,7 @@ def main():
                                         "sample": f"failed: {ex!r}"}
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
 
 

@@ -48,15 +48,43 @@ __device__ inline void load_staged(const GeomRec* __restrict__ rec, uint32_t id,
   }
 }
 
-// which of the tile's four 8x8 sub-blocks can the Gaussian reach (bit k = sub-block k)
-__device__ inline uint32_t subblock_mask(float gx, float gy, float ex, float ey, float tx0, float ty0) {
+// Smallest value of q(d) = cxx dx^2 + 2 cxy dx dy + cyy dy^2 over the rectangle [x0,x1] x [y0,y1] of
+// offsets d = p - mean (the conic is positive definite, so off-centre the minimum sits on an edge).
+__device__ inline float qmin_rect(float cxx, float cxy, float cyy, float icxx, float icyy, float dx0, float dx1,
+                                  float dy0, float dy1) {
+  if (dx0 <= 0.0f && dx1 >= 0.0f && dy0 <= 0.0f && dy1 >= 0.0f) return 0.0f;
+  auto q = [&](float dx, float dy) { return cxx * dx * dx + 2.0f * cxy * dx * dy + cyy * dy * dy; };
+  auto cl = [](float v, float lo, float hi) { return fminf(hi, fmaxf(lo, v)); };
+  const float a = q(dx0, cl(-cxy * dx0 * icyy, dy0, dy1));
+  const float b = q(dx1, cl(-cxy * dx1 * icyy, dy0, dy1));
+  const float c = q(cl(-cxy * dy0 * icxx, dx0, dx1), dy0);
+  const float d = q(cl(-cxy * dy1 * icxx, dx0, dx1), dy1);
+  return fminf(fminf(a, b), fminf(c, d));
+}
+
+// Which of the tile's four 8x8 sub-blocks can the Gaussian reach with alpha >= 1/255 (bit k = sub-block k).
+// Two conservative tests: the bounding box of the alpha >= 1/255 ellipse (GeomRec.ext_x / ext_y), then the exact
+// ellipse-vs-rectangle test q_min <= 2 ln(255 opacity) with a relative + absolute safety margin.  A skipped
+// sub-block would have been rejected pixel by pixel by the alpha test, so results do not change.
+__device__ inline uint32_t subblock_mask(float gx, float gy, float ex, float ey, float cxx, float cxy, float cyy,
+                                         float opacity, float tx0, float ty0) {
   if (ex < 0.0f) return 0u;
   const bool xl = (gx + ex >= tx0) && (gx - ex <= tx0 + 7.0f);
   const bool xr = (gx + ex >= tx0 + 8.0f) && (gx - ex <= tx0 + 15.0f);
   const bool yt = (gy + ey >= ty0) && (gy - ey <= ty0 + 7.0f);
   const bool yb = (gy + ey >= ty0 + 8.0f) && (gy - ey <= ty0 + 15.0f);
-  return (uint32_t)(xl && yt) | ((uint32_t)(xr && yt) << 1) | ((uint32_t)(xl && yb) << 2) |
-         ((uint32_t)(xr && yb) << 3);
+  uint32_t m = (uint32_t)(xl && yt) | ((uint32_t)(xr && yt) << 1) | ((uint32_t)(xl && yb) << 2) |
+               ((uint32_t)(xr && yb) << 3);
+  if (m == 0u) return 0u;
+  const float t = 2.0f * 0.6931472f * __log2f(255.0f * opacity) * 1.001f + 2e-3f;
+  const float icxx = __builtin_amdgcn_rcpf(cxx), icyy = __builtin_amdgcn_rcpf(cyy);
+  const float ax0 = tx0 - gx, ay0 = ty0 - gy;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float dx0 = ax0 + 8.0f * (float)(k & 1), dy0 = ay0 + 8.0f * (float)(k >> 1);
+    if (qmin_rect(cxx, cxy, cyy, icxx, icyy, dx0, dx0 + 7.0f, dy0, dy0 + 7.0f) > t) m &= ~(1u << k);
+  }
+  return m;
 }
 
 // LDS image of a staged instance.  The quadratic form is kept pre-scaled by log2(e) so that the
@@ -121,7 +149,7 @@ __device__ __forceinline__ void render_fwd_tile(const int tile, float4* sA, floa
   for (uint32_t pos = start; pos < end && live; pos += BATCH) {
     const bool have = pos + lane < end;
     if (STATS) st_staged += min((uint32_t)BATCH, end - pos);
-    const uint32_t m = have ? subblock_mask(st.q0.x, st.q0.y, st.q2.y, st.q2.z, tx0, ty0) : 0u;
+    const uint32_t m = have ? subblock_mask(st.q0.x, st.q0.y, st.q2.y, st.q2.z, st.q0.z, st.q0.w, st.q1.x, st.q1.y, tx0, ty0) : 0u;
     LdsRec lr;
     make_lds(st, lr);
     __builtin_amdgcn_wave_barrier();   // LDS ops of one wave execute in order: no hardware barrier needed
@@ -326,7 +354,7 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, floa
 
   while (hi > 0) {
     const bool have = lo + lane < hi;
-    const uint32_t m = have ? subblock_mask(st.q0.x, st.q0.y, st.q2.y, st.q2.z, tx0, ty0) : 0u;
+    const uint32_t m = have ? subblock_mask(st.q0.x, st.q0.y, st.q2.y, st.q2.z, st.q0.z, st.q0.w, st.q1.x, st.q1.y, tx0, ty0) : 0u;
     // slot of this instance in the unsorted instance array (the order duplicateWithKeys emitted)
     const uint32_t rw = st.rect_wh & 0xffffu;
     const uint32_t slot = __float_as_uint(st.q2.w) + ((uint32_t)tile_y - (st.rect_min >> 16)) * rw +
