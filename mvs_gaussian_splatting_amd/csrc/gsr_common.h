@@ -87,8 +87,8 @@ struct ImageLayout {
   }
 };
 
-constexpr int SORT_THREADS = 256;
-constexpr int SORT_ITEMS = 16;
+constexpr int SORT_THREADS = 512;
+constexpr int SORT_ITEMS = 8;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;   // keys per sort block
 constexpr int RADIX_BITS = 9;   // 45-bit keys at 1080p (13 tile bits + 32 depth bits) sort in 5 passes
 constexpr int RADIX = 1 << RADIX_BITS;
