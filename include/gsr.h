@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 2
+#define GSR_ABI_VERSION 3
 
 enum {
   GSR_OK = 0,
@@ -70,7 +70,14 @@ typedef struct GsrParams {
    * scene/gaussian_model.py:151-183 and their autograd): */
   const float* shs_rest;       /* NULL, or device [P,M-1,3] (16-byte aligned): then `shs` is [P,1,3] (f_dc) */
   int32_t act_flags;           /* GSR_ACT_*: inputs are RAW parameters, the activation (and its gradient) is applied here */
+  int32_t binning_mode;        /* GSR_BINNING_TWO_LEVEL (default) or GSR_BINNING_KEYS64; same value in every call of a frame */
 } GsrParams;
+
+enum {
+  GSR_BINNING_TWO_LEVEL = 0,   /* depth-sort the visible Gaussians (u32 keys), emit instances in depth order, stable
+                                  partition by tile id (u32 keys): same lists as KEYS64 for ~2.5x less sort traffic */
+  GSR_BINNING_KEYS64 = 1       /* upstream layout: duplicateWithKeys + radix sort of u64 tile<<32|depth keys */
+};
 
 enum {
   GSR_ACT_SCALE_EXP = 1,       /* scales    = exp(raw)              scene/gaussian_model.py:34,151-153 */
@@ -103,24 +110,26 @@ const char* gsr_build_info(void);       /* "gfx950 ..." */
 /* ---- workspace sizing (bytes; all workspaces must be 256-byte aligned) ----------------- */
 size_t gsr_geom_bytes(int32_t P);                        /* per-Gaussian state (upstream "geomBuffer") */
 size_t gsr_image_bytes(int32_t width, int32_t height);   /* per-pixel + per-tile state ("imgBuffer") */
-size_t gsr_binning_bytes(uint32_t num_rendered, int32_t width, int32_t height); /* keys/values/sort scratch ("binningBuffer") */
+size_t gsr_binning_bytes(uint32_t num_rendered, uint32_t num_visible, int32_t width, int32_t height,
+                         int32_t binning_mode);          /* keys/values/sort scratch ("binningBuffer") */
 size_t gsr_backward_bytes(int32_t P, uint32_t num_rendered); /* per-instance gradient rows + flags */
 
 /* ---- forward -------------------------------------------------------------------------- */
 /* Stage 1: preprocess (cull, project, cov3D->cov2D->conic, radius, tile rect, SH->RGB) and the
- * prefix sum of tiles_touched.  Writes radii[P] (int32) and *num_rendered (host).  Blocks the
- * calling thread until the 4-byte count has been read back (the one sync of the forward). */
+ * prefix sum of tiles_touched.  Writes radii[P] (int32), *num_rendered (instances) and *num_visible (host).
+ * Blocks the calling thread until the two counts have been read back (the one sync of the forward). */
 int gsr_forward_preprocess(const GsrParams* p, void* geom_ws, int32_t* radii, void* stream,
-                           uint32_t* num_rendered);
+                           uint32_t* num_rendered, uint32_t* num_visible);
 
-/* Stage 2: duplicateWithKeys, 64-bit radix sort, identifyTileRanges, per-tile compositing.
- * Writes out_color[3,H,W].  bin_ws must hold gsr_binning_bytes(num_rendered, W, H). */
+/* Stage 2: tile binning (see binning_mode), identifyTileRanges, per-tile compositing.
+ * Writes out_color[3,H,W].  bin_ws must hold gsr_binning_bytes(num_rendered, num_visible, W, H, mode). */
 int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t bin_ws_bytes,
-                       void* img_ws, uint32_t num_rendered, float* out_color, void* stream);
+                       void* img_ws, uint32_t num_rendered, uint32_t num_visible, float* out_color, void* stream);
 
 /* ---- backward ------------------------------------------------------------------------- */
 int gsr_backward(const GsrParams* p, const int32_t* radii, const void* geom_ws, const void* bin_ws,
-                 const void* img_ws, uint32_t num_rendered, const float* dL_dout_color /* [3,H,W] */,
+                 const void* img_ws, uint32_t num_rendered, uint32_t num_visible,
+                 const float* dL_dout_color /* [3,H,W] */,
                  void* bwd_ws, size_t bwd_ws_bytes, const GsrGrads* grads, void* stream);
 
 /* ---- unit entry points (each stage callable on its own; used by the parity tests) ------- */
@@ -134,7 +143,9 @@ int gsr_debug_read_geom(const void* geom_ws, int32_t P, float* xy /*[P,2]*/, flo
                         float* rgb /*[P,3]*/, float* depth /*[P]*/, uint32_t* tiles_touched /*[P]*/,
                         uint32_t* point_offsets /*[P]*/, uint32_t* rect /*[P,4] x0,y0,x1,y1*/,
                         uint32_t* clamped /*[P]*/, void* stream);
-int gsr_debug_read_binning(const void* bin_ws, uint32_t num_rendered, int32_t width, int32_t height,
+/* keys_sorted are the (tile<<32|depth) keys of the sorted instances (rebuilt from the result in two-level mode) */
+int gsr_debug_read_binning(const void* geom_ws, int32_t P, const void* bin_ws, uint32_t num_rendered,
+                           uint32_t num_visible, int32_t width, int32_t height, int32_t binning_mode,
                            uint64_t* keys_sorted, uint32_t* point_list, void* stream);
 int gsr_debug_read_image(const void* img_ws, int32_t width, int32_t height, float* final_T,
                          uint32_t* n_contrib, uint32_t* ranges /*[T,2]*/, void* stream);
@@ -143,7 +154,8 @@ int gsr_debug_read_image(const void* img_ws, int32_t width, int32_t height, floa
  * [0] instances in all tile lists, [1] staged into LDS, [2] visited after the sub-block cull,
  * [3] sub-block evaluations, [4] evaluations with at least one contributing lane, [5] sum of per-tile last contributor */
 int gsr_debug_render_stats(const GsrParams* p, const void* geom_ws, const void* bin_ws, void* img_ws,
-                           uint32_t num_rendered, float* out_color, unsigned long long* stats, void* stream);
+                           uint32_t num_rendered, uint32_t num_visible, float* out_color, unsigned long long* stats,
+                           void* stream);
 
 /* ---- stage timers (opt-in; HIP events recorded on the call's stream around each stage) ------ */
 enum {

@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class GsrParams(C.Structure):
@@ -25,7 +25,7 @@ class GsrParams(C.Structure):
         ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
         ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
         ("campos", C.c_void_p), ("bg", C.c_void_p), ("profile", C.c_void_p),
-        ("shs_rest", C.c_void_p), ("act_flags", C.c_int32),
+        ("shs_rest", C.c_void_p), ("act_flags", C.c_int32), ("binning_mode", C.c_int32),
     ]
 
 
@@ -37,6 +37,7 @@ class GsrGrads(C.Structure):
     ]
 
 ACT_SCALE_EXP, ACT_ROT_NORMALIZE, ACT_OPACITY_SIGMOID = 1, 2, 4
+BINNING_TWO_LEVEL, BINNING_KEYS64 = 0, 1
 
 
 # name -> (restype, argtypes); every symbol include/gsr.h declares
@@ -46,26 +47,26 @@ SYMBOLS = {
     "gsr_build_info": (C.c_char_p, []),
     "gsr_geom_bytes": (C.c_size_t, [C.c_int32]),
     "gsr_image_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
-    "gsr_binning_bytes": (C.c_size_t, [C.c_uint32, C.c_int32, C.c_int32]),
+    "gsr_binning_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_int32]),
     "gsr_backward_bytes": (C.c_size_t, [C.c_int32, C.c_uint32]),
     "gsr_forward_preprocess": (C.c_int, [C.POINTER(GsrParams), C.c_void_p, C.c_void_p, C.c_void_p,
-                                         C.POINTER(C.c_uint32)]),
+                                         C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "gsr_forward_render": (C.c_int, [C.POINTER(GsrParams), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
-                                     C.c_uint32, C.c_void_p, C.c_void_p]),
+                                     C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "gsr_backward": (C.c_int, [C.POINTER(GsrParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
-                               C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(GsrGrads), C.c_void_p]),
+                               C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(GsrGrads), C.c_void_p]),
     "gsr_sort_scratch_bytes": (C.c_size_t, [C.c_uint32]),
     "gsr_sort_pairs_u64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32,
                                      C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "gsr_debug_read_geom": (C.c_int, [C.c_void_p, C.c_int32] + [C.c_void_p] * 9),
-    "gsr_debug_read_binning": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
-                                         C.c_void_p]),
+    "gsr_debug_read_binning": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
+                                         C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsr_debug_read_image": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
     "gsr_l1_loss_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p,
                                       C.c_void_p]),
     "gsr_debug_render_stats": (C.c_int, [C.POINTER(GsrParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
-                                         C.c_void_p, C.c_void_p, C.c_void_p]),
+                                         C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsr_profile_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "gsr_profile_destroy": (C.c_int, [C.c_void_p]),
     "gsr_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),

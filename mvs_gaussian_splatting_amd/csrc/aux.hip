@@ -54,13 +54,24 @@ __global__ __launch_bounds__(256) void densify_stats_kernel(int P, const float* 
   }
 }
 
-__global__ __launch_bounds__(256) void unpack_geom_kernel(int P, const GeomRec* __restrict__ rec,
-                                                          const BinInfo* __restrict__ bin,
-                                                          const uint32_t* __restrict__ offsets, float* xy,
-                                                          float* conic_opacity, float* rgb, float* depth,
-                                                          uint32_t* tiles, uint32_t* point_offsets, uint32_t* rect,
-                                                          uint32_t* clamped) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(PRE_BLOCK) void unpack_geom_kernel(int P, const GeomRec* __restrict__ rec,
+                                                                const BinInfo* __restrict__ bin,
+                                                                const uint32_t* __restrict__ block_offs, float* xy,
+                                                                float* conic_opacity, float* rgb, float* depth,
+                                                                uint32_t* tiles, uint32_t* point_offsets,
+                                                                uint32_t* rect, uint32_t* clamped) {
+  __shared__ uint32_t wave_tot[PRE_BLOCK / WAVE];
+  const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  {   // upstream's point_offsets: inclusive scan of tiles_touched in index order (block level + in-block)
+    const uint32_t t = i < P ? bin[i].tiles : 0u;
+    const uint32_t inc = wave_incl_scan_u32(t);
+    const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+    if (lane == WAVE - 1) wave_tot[wid] = inc;
+    __syncthreads();
+    uint32_t base = block_offs[blockIdx.x];
+    for (int w = 0; w < wid; ++w) base += wave_tot[w];
+    if (point_offsets && i < P) point_offsets[i] = base + inc;
+  }
   if (i >= P) return;
   const BinInfo b = bin[i];
   const bool vis = b.tiles != 0;
@@ -74,7 +85,6 @@ __global__ __launch_bounds__(256) void unpack_geom_kernel(int P, const GeomRec* 
   if (rgb) { rgb[3 * i] = vis ? g.r : 0.f; rgb[3 * i + 1] = vis ? g.g : 0.f; rgb[3 * i + 2] = vis ? g.b : 0.f; }
   if (depth) depth[i] = vis ? b.depth : 0.f;
   if (tiles) tiles[i] = b.tiles;
-  if (point_offsets) point_offsets[i] = offsets[i];
   if (rect) {
     const uint32_t x0 = b.rect_min & 0xffffu, y0 = b.rect_min >> 16;
     rect[4 * i] = vis ? x0 : 0u; rect[4 * i + 1] = vis ? y0 : 0u;
@@ -97,12 +107,12 @@ void launch_densify_stats(int P, const float* dL_dmeans2D, const int32_t* radii,
   hipLaunchKernelGGL(densify_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, dL_dmeans2D, radii, accum, denom,
                      max_radii2D);
 }
-void launch_unpack_geom(int P, const GeomRec* rec, const BinInfo* bin, const uint32_t* offsets, float* xy,
+void launch_unpack_geom(int P, const GeomRec* rec, const BinInfo* bin, const uint32_t* block_offs, float* xy,
                         float* conic_opacity, float* rgb, float* depth, uint32_t* tiles, uint32_t* point_offsets,
                         uint32_t* rect, uint32_t* clamped, hipStream_t s) {
   if (P <= 0) return;
-  hipLaunchKernelGGL(unpack_geom_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, rec, bin, offsets, xy, conic_opacity,
-                     rgb, depth, tiles, point_offsets, rect, clamped);
+  hipLaunchKernelGGL(unpack_geom_kernel, dim3((P + PRE_BLOCK - 1) / PRE_BLOCK), dim3(PRE_BLOCK), 0, s, P, rec, bin,
+                     block_offs, xy, conic_opacity, rgb, depth, tiles, point_offsets, rect, clamped);
 }
 
 }  // namespace gsr

@@ -74,6 +74,139 @@ __global__ __launch_bounds__(PRE_BLOCK) void duplicate_with_keys_kernel(int P, i
 }
 
 // ------------------------------------------------------------------------------------------
+// Two-level binning (mode 0).  Same point lists and tile ranges as sorting 64-bit (tile, depth) keys, for
+// ~2.5x less memory traffic: the per-instance data that goes through a multi-pass sort shrinks from 12 bytes x
+// 5-6 passes to 8 bytes x 2 passes, because the depth order is established once per Gaussian, not per instance.
+//   1. compact_visible      : (depth bits, index) of the visible Gaussians, in index order
+//   2. sort by depth        : stable LSD radix sort of V (u32, u32) pairs, 32 bits
+//   3. gather_tiles + scan  : tiles_touched in depth order -> first slot of every Gaussian (depth-major slots)
+//   4. emit_instances       : (tile id, index) per overlapped tile, y outer / x inner, in depth order
+//   5. sort by tile         : stable sort on ceil(log2 T) bits -> lists ordered by (tile, depth, index)
+// Stability of both sorts reproduces the tie order of a stable 64-bit sort of index-ordered pairs.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PRE_BLOCK) void compact_visible_kernel(int P, const BinInfo* __restrict__ bin,
+                                                                    const uint32_t* __restrict__ block_vis_offs,
+                                                                    const uint32_t* __restrict__ block_offs,
+                                                                    GeomRec* __restrict__ rec,
+                                                                    uint32_t* __restrict__ dkey,
+                                                                    uint32_t* __restrict__ didx) {
+  __shared__ uint32_t wave_tot[PRE_BLOCK / WAVE];
+  __shared__ uint32_t wave_tiles[PRE_BLOCK / WAVE];
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+  const int idx = blockIdx.x * PRE_BLOCK + tid;
+  BinInfo bi{0u, 0u, 0.0f, 0u};
+  if (idx < P) bi = bin[idx];
+  const uint32_t vis = bi.tiles != 0u;
+  const uint32_t inc = wave_incl_scan_u32(vis);
+  const uint32_t tinc = wave_incl_scan_u32(bi.tiles);
+  if (lane == WAVE - 1) { wave_tot[wid] = inc; wave_tiles[wid] = tinc; }
+  __syncthreads();
+  uint32_t base = block_vis_offs[blockIdx.x];
+  uint32_t tbase = block_offs[blockIdx.x];
+#pragma unroll
+  for (int w = 0; w < PRE_BLOCK / WAVE; ++w)
+    if (w < wid) { base += wave_tot[w]; tbase += wave_tiles[w]; }
+  if (vis) {
+    const uint32_t o = base + inc - 1u;
+    dkey[o] = __float_as_uint(bi.depth);
+    didx[o] = (uint32_t)idx;
+    // slot range of this Gaussian's per-instance gradient rows: index-major (any bijection works; this one is
+    // written with neighbouring lanes touching neighbouring records)
+    rec[idx].offs_excl = tbase + tinc - bi.tiles;
+  }
+}
+
+__global__ __launch_bounds__(PRE_BLOCK) void gather_tiles_kernel(uint32_t V, const uint32_t* __restrict__ didx,
+                                                                 const BinInfo* __restrict__ bin,
+                                                                 uint32_t* __restrict__ tiles_sorted,
+                                                                 uint2* __restrict__ rect_sorted,
+                                                                 uint32_t* __restrict__ block_sums2) {
+  __shared__ uint32_t wave_tot[PRE_BLOCK / WAVE];
+  const uint32_t i = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  uint32_t t = 0;
+  if (i < V) {
+    const BinInfo bi = bin[didx[i]];          // the one random gather of the binning stage
+    t = bi.tiles;
+    tiles_sorted[i] = t;
+    rect_sorted[i] = make_uint2(bi.rect_min, bi.rect_wh);
+  }
+  const uint32_t ws = wave_reduce_add_u32(t);
+  if ((threadIdx.x & (WAVE - 1)) == 0) wave_tot[threadIdx.x / WAVE] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t s = 0;
+#pragma unroll
+    for (int w = 0; w < PRE_BLOCK / WAVE; ++w) s += wave_tot[w];
+    block_sums2[blockIdx.x] = s;
+  }
+}
+
+__global__ __launch_bounds__(PRE_BLOCK) void emit_instances_kernel(uint32_t V, int grid_x,
+                                                                   const uint32_t* __restrict__ didx,
+                                                                   const uint32_t* __restrict__ tiles_sorted,
+                                                                   const uint2* __restrict__ rect_sorted,
+                                                                   const uint32_t* __restrict__ block_offs2,
+                                                                   uint32_t* __restrict__ inst_tile,
+                                                                   uint32_t* __restrict__ inst_g) {
+  __shared__ uint32_t wave_tot[PRE_BLOCK / WAVE];
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+  const uint32_t i = blockIdx.x * PRE_BLOCK + tid;
+  uint32_t g = 0, tiles = 0;
+  BinInfo bi{0u, 0u, 0.0f, 0u};
+  if (i < V) {
+    g = didx[i];
+    tiles = tiles_sorted[i];
+    const uint2 rr = rect_sorted[i];
+    bi.rect_min = rr.x;
+    bi.rect_wh = rr.y;
+  }
+  const uint32_t inc = wave_incl_scan_u32(tiles);
+  if (lane == WAVE - 1) wave_tot[wid] = inc;
+  __syncthreads();
+  uint32_t base = block_offs2[blockIdx.x];
+#pragma unroll
+  for (int w = 0; w < PRE_BLOCK / WAVE; ++w)
+    if (w < wid) base += wave_tot[w];
+  const uint32_t off = base + inc - tiles;   // first instance of this Gaussian in the depth-ordered array
+  const uint32_t x0 = bi.rect_min & 0xffffu, y0 = bi.rect_min >> 16;
+  const uint32_t w = bi.rect_wh & 0xffffu;
+  if (tiles && tiles <= DUP_SMALL) {
+    uint32_t o = off;
+    const uint32_t h = bi.rect_wh >> 16;
+    for (uint32_t y = y0; y < y0 + h; ++y)
+      for (uint32_t x = x0; x < x0 + w; ++x) {
+        inst_tile[o] = y * (uint32_t)grid_x + x;
+        inst_g[o] = g;
+        ++o;
+      }
+  }
+  unsigned long long big = __ballot(tiles > DUP_SMALL);   // large splats: the whole wave emits
+  while (big) {
+    const int src = __ffsll((long long)big) - 1;
+    big &= big - 1;
+    const uint32_t s_tiles = __shfl(tiles, src, WAVE);
+    const uint32_t s_off = __shfl(off, src, WAVE);
+    const uint32_t s_min = __shfl(bi.rect_min, src, WAVE);
+    const uint32_t s_w = __shfl(w, src, WAVE);
+    const uint32_t s_g = __shfl(g, src, WAVE);
+    const uint32_t sx0 = s_min & 0xffffu, sy0 = s_min >> 16;
+    for (uint32_t k = (uint32_t)lane; k < s_tiles; k += WAVE) {
+      inst_tile[s_off + k] = (sy0 + k / s_w) * (uint32_t)grid_x + (sx0 + k % s_w);
+      inst_g[s_off + k] = s_g;
+    }
+  }
+}
+
+// debug: the 64-bit keys a (tile, depth) sort would have produced, rebuilt from the two-level result
+__global__ __launch_bounds__(256) void reconstruct_keys_kernel(uint32_t R, const uint32_t* __restrict__ tile_sorted,
+                                                               const uint32_t* __restrict__ point_list,
+                                                               const BinInfo* __restrict__ bin,
+                                                               uint64_t* __restrict__ keys) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < R) keys[i] = ((uint64_t)tile_sorted[i] << 32) | (uint64_t)__float_as_uint(bin[point_list[i]].depth);
+}
+
+// ------------------------------------------------------------------------------------------
 // Radix sort, one 8-bit digit per pass, three kernels per pass (no inter-workgroup waiting):
 //   hist    : per-block digit histogram      -> hist[digit][block]
 //   rowscan : exclusive scan of every digit row over blocks, row totals -> totals[digit]
@@ -82,9 +215,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void duplicate_with_keys_kernel(int P, i
 // Item order inside a block tile: wave w owns [w*1024, w*1024+1024); item i of lane l is
 // element i*64 + l of that range, so (i, l) lexicographic == memory order (stability).
 // ------------------------------------------------------------------------------------------
-__device__ inline uint32_t digit_of(uint64_t k, int shift, uint32_t mask) { return (uint32_t)(k >> shift) & mask; }
+template <typename KeyT>
+__device__ inline uint32_t digit_of(KeyT k, int shift, uint32_t mask) { return (uint32_t)(k >> shift) & mask; }
 
-__global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint64_t* __restrict__ keys, uint32_t n,
+template <typename KeyT>
+__global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT* __restrict__ keys, uint32_t n,
                                                                   int shift, uint32_t mask, uint32_t nblocks,
                                                                   uint32_t* __restrict__ hist) {
   __shared__ uint32_t h[RADIX];
@@ -93,11 +228,11 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint64_t
   for (int d = tid; d < RADIX; d += SORT_THREADS) h[d] = 0;
   __syncthreads();
   const uint32_t base = blockIdx.x * SORT_TILE;
-  uint64_t kk[SORT_ITEMS];
+  KeyT kk[SORT_ITEMS];
 #pragma unroll
   for (int i = 0; i < SORT_ITEMS; ++i) {       // all loads in flight before the first LDS atomic
     const uint32_t g = base + i * SORT_THREADS + tid;
-    kk[i] = g < n ? keys[g] : 0ull;
+    kk[i] = g < n ? keys[g] : (KeyT)0;
   }
 #pragma unroll
   for (int i = 0; i < SORT_ITEMS; ++i) {
@@ -137,13 +272,14 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(uint32_t* __restrict
   if (tid == 0) totals[blockIdx.x] = carry_s;
 }
 
+template <typename KeyT>
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
-    const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t* __restrict__ keys_out,
+    const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, KeyT* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, uint32_t n, int shift, uint32_t mask, uint32_t nblocks,
     const uint32_t* __restrict__ hist,
     const uint32_t* __restrict__ totals) {
   constexpr int NW = SORT_THREADS / WAVE;
-  __shared__ uint64_t xbuf[SORT_TILE];        // exchange buffer: keys first, then reused for the values
+  __shared__ KeyT xbuf[SORT_TILE];            // exchange buffer: keys first, then reused for the values
   __shared__ uint32_t wave_hist[NW][RADIX];   // per-wave digit counts, then exclusive wave prefixes
   __shared__ uint32_t digit_start[RADIX];     // first local slot of every digit
   __shared__ uint32_t global_base[RADIX];     // global position of the block's first item of the digit
@@ -159,7 +295,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     for (int d = tid; d < RADIX; d += SORT_THREADS) wave_hist[w][d] = 0;
   __syncthreads();
 
-  uint64_t k[SORT_ITEMS];
+  KeyT k[SORT_ITEMS];
   uint32_t v[SORT_ITEMS];
   uint32_t rank[SORT_ITEMS];
 #pragma unroll
@@ -264,7 +400,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const uint32_t s = i * SORT_THREADS + tid;
     dst[i] = 0;
     if (s < count) {
-      const uint64_t kk = xbuf[s];
+      const KeyT kk = xbuf[s];
       const uint32_t d = digit_of(kk, shift, mask);
       dst[i] = global_base[d] + (s - digit_start[d]);
       keys_out[dst[i]] = kk;
@@ -289,15 +425,16 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
 // identifyTileRanges (A.3): ranges[tile] = [first, last+1) of its run in the sorted keys.
 // The caller zero-fills `ranges` (empty tiles stay (0,0)).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void identify_tile_ranges_kernel(uint32_t R, const uint64_t* __restrict__ keys,
+template <typename KeyT, int TILE_SHIFT>
+__global__ __launch_bounds__(256) void identify_tile_ranges_kernel(uint32_t R, const KeyT* __restrict__ keys,
                                                                    uint2* __restrict__ ranges) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= R) return;
-  const uint32_t cur = (uint32_t)(keys[i] >> 32);
+  const uint32_t cur = (uint32_t)(keys[i] >> TILE_SHIFT);
   if (i == 0) {
     ranges[cur].x = 0;
   } else {
-    const uint32_t prev = (uint32_t)(keys[i - 1] >> 32);
+    const uint32_t prev = (uint32_t)(keys[i - 1] >> TILE_SHIFT);
     if (cur != prev) {
       ranges[prev].y = i;
       ranges[cur].x = i;
@@ -349,26 +486,63 @@ void launch_duplicate_with_keys(int P, int grid_x, const BinInfo* bin, const uin
                        point_offsets, keys, vals);
 }
 
-bool launch_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, uint32_t n,
-                       int end_bit, void* scratch, hipStream_t s) {
+template <typename KeyT>
+static bool sort_pairs_impl(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t* vals_b, uint32_t n, int end_bit,
+                            void* scratch, hipStream_t s) {
   if (n == 0 || end_bit <= 0) return false;
   const SortLayout L(n);
   uint32_t* hist = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + L.hist);
   uint32_t* totals = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + L.totals);
   const int passes = sort_passes(end_bit);
-  uint64_t* kin = keys_a; uint32_t* vin = vals_a; uint64_t* kout = keys_b; uint32_t* vout = vals_b;
+  KeyT* kin = keys_a; uint32_t* vin = vals_a; KeyT* kout = keys_b; uint32_t* vout = vals_b;
   for (int pass = 0; pass < passes; ++pass) {
     const int shift = pass * RADIX_BITS;
     const int nbits = end_bit - shift < RADIX_BITS ? end_bit - shift : RADIX_BITS;   // ignore bits >= end_bit
     const uint32_t mask = (1u << nbits) - 1u;
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(L.nblocks), dim3(SORT_THREADS), 0, s, kin, n, shift, mask, L.nblocks, hist);
+    hipLaunchKernelGGL(radix_hist_kernel<KeyT>, dim3(L.nblocks), dim3(SORT_THREADS), 0, s, kin, n, shift, mask,
+                       L.nblocks, hist);
     hipLaunchKernelGGL(radix_rowscan_kernel, dim3(RADIX), dim3(256), 0, s, hist, L.nblocks, totals);
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(L.nblocks), dim3(SORT_THREADS), 0, s, kin, vin, kout, vout, n, shift,
-                       mask, L.nblocks, hist, totals);
-    uint64_t* tk = kin; kin = kout; kout = tk;
+    hipLaunchKernelGGL(radix_scatter_kernel<KeyT>, dim3(L.nblocks), dim3(SORT_THREADS), 0, s, kin, vin, kout, vout, n,
+                       shift, mask, L.nblocks, hist, totals);
+    KeyT* tk = kin; kin = kout; kout = tk;
     uint32_t* tv = vin; vin = vout; vout = tv;
   }
   return (passes & 1) != 0;
+}
+bool launch_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, uint32_t n,
+                       int end_bit, void* scratch, hipStream_t s) {
+  return sort_pairs_impl<uint64_t>(keys_a, vals_a, keys_b, vals_b, n, end_bit, scratch, s);
+}
+bool launch_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n,
+                           int end_bit, void* scratch, hipStream_t s) {
+  return sort_pairs_impl<uint32_t>(keys_a, vals_a, keys_b, vals_b, n, end_bit, scratch, s);
+}
+
+void launch_compact_visible(int P, const BinInfo* bin, const uint32_t* block_vis_offs, const uint32_t* block_offs,
+                            GeomRec* rec, uint32_t* dkey, uint32_t* didx, hipStream_t s) {
+  const int nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+  if (nb > 0)
+    hipLaunchKernelGGL(compact_visible_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, P, bin, block_vis_offs, block_offs, rec,
+                       dkey, didx);
+}
+void launch_gather_tiles(uint32_t V, const uint32_t* didx, const BinInfo* bin, uint32_t* tiles_sorted, uint2* rect_sorted,
+                         uint32_t* block_sums2, hipStream_t s) {
+  const uint32_t nb = (V + PRE_BLOCK - 1) / PRE_BLOCK;
+  if (nb)
+    hipLaunchKernelGGL(gather_tiles_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, V, didx, bin, tiles_sorted, rect_sorted,
+                       block_sums2);
+}
+void launch_emit_instances(uint32_t V, int grid_x, const uint32_t* didx, const uint32_t* tiles_sorted,
+                           const uint2* rect_sorted, const uint32_t* block_offs2, uint32_t* inst_tile, uint32_t* inst_g,
+                           hipStream_t s) {
+  const uint32_t nb = (V + PRE_BLOCK - 1) / PRE_BLOCK;
+  if (nb)
+    hipLaunchKernelGGL(emit_instances_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, V, grid_x, didx, tiles_sorted, rect_sorted,
+                       block_offs2, inst_tile, inst_g);
+}
+void launch_reconstruct_keys(uint32_t R, const uint32_t* tile_sorted, const uint32_t* point_list, const BinInfo* bin,
+                             uint64_t* keys, hipStream_t s) {
+  if (R) hipLaunchKernelGGL(reconstruct_keys_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, tile_sorted, point_list, bin, keys);
 }
 
 void launch_build_tile_order(int tiles, const uint2* ranges, uint32_t* order, hipStream_t s) {
@@ -377,7 +551,13 @@ void launch_build_tile_order(int tiles, const uint2* ranges, uint32_t* order, hi
 
 void launch_identify_tile_ranges(uint32_t R, const uint64_t* keys, uint2* ranges, hipStream_t s) {
   if (R == 0) return;
-  hipLaunchKernelGGL(identify_tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, keys, ranges);
+  hipLaunchKernelGGL((identify_tile_ranges_kernel<uint64_t, 32>), dim3((R + 255) / 256), dim3(256), 0, s, R, keys,
+                     ranges);
+}
+void launch_identify_tile_ranges_u32(uint32_t R, const uint32_t* tiles, uint2* ranges, hipStream_t s) {
+  if (R == 0) return;
+  hipLaunchKernelGGL((identify_tile_ranges_kernel<uint32_t, 0>), dim3((R + 255) / 256), dim3(256), 0, s, R, tiles,
+                     ranges);
 }
 
 }  // namespace gsr

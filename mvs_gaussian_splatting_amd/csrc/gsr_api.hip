@@ -66,6 +66,8 @@ int validate(const GsrParams* p) {
   } else if (p->shs_rest) {
     return fail(GSR_E_BADARG, "shs_rest given without shs");
   }
+  if (p->binning_mode != GSR_BINNING_TWO_LEVEL && p->binning_mode != GSR_BINNING_KEYS64)
+    return fail(GSR_E_BADARG, "unknown binning_mode");
   if ((p->act_flags & (GSR_ACT_SCALE_EXP | GSR_ACT_ROT_NORMALIZE)) && !p->scales)
     return fail(GSR_E_BADARG, "scale / rotation activations need the scales + rotations inputs");
   if (p->rotations && ((uintptr_t)p->rotations & 15u) != 0) return fail(GSR_E_ALIGN, "rotations must be 16-byte aligned");
@@ -103,9 +105,26 @@ T* at(void* base, size_t off) { return reinterpret_cast<T*>(static_cast<char*>(b
 template <typename T>
 const T* at(const void* base, size_t off) { return reinterpret_cast<const T*>(static_cast<const char*>(base) + off); }
 
-bool sorted_in_b(int W, int H) {
+// where the sorted point list (and the sorted tile ids / keys) of a frame ended up
+struct SortedViews {
+  const uint32_t* point_list;
+  const uint32_t* tile_sorted;   // mode 0
+  const uint64_t* keys_sorted;   // mode 1
+};
+SortedViews sorted_views(const void* bin_ws, uint32_t R, uint32_t V, int W, int H, int mode) {
   const ImageLayout I(W, H);
-  return (sort_passes(32 + tile_bits(I.tiles)) & 1) != 0;
+  const BinLayout B(R, V, mode);
+  SortedViews v{nullptr, nullptr, nullptr};
+  if (mode == GSR_BINNING_KEYS64) {
+    const bool in_b = (sort_passes(32 + tile_bits(I.tiles)) & 1) != 0;
+    v.point_list = at<uint32_t>(bin_ws, in_b ? B.vals_b : B.vals_a);
+    v.keys_sorted = at<uint64_t>(bin_ws, in_b ? B.keys_b : B.keys_a);
+  } else {
+    const bool in_b = (sort_passes(tile_bits(I.tiles)) & 1) != 0;
+    v.point_list = at<uint32_t>(bin_ws, in_b ? B.ig_b : B.ig_a);
+    v.tile_sorted = at<uint32_t>(bin_ws, in_b ? B.itile_b : B.itile_a);
+  }
+  return v;
 }
 }  // namespace
 
@@ -113,18 +132,22 @@ extern "C" {
 
 int gsr_abi_version(void) { return GSR_ABI_VERSION; }
 const char* gsr_last_error(void) { return g_err.c_str(); }
-const char* gsr_build_info(void) { return "libgsr_hip gfx950 wave64 tile16 radix9 (HIP " __DATE__ ")"; }
+const char* gsr_build_info(void) { return "libgsr_hip gfx950 wave64 tile16 radix9 two-level-binning (HIP " __DATE__ ")"; }
 
 size_t gsr_geom_bytes(int32_t P) { return GeomLayout(P < 0 ? 0 : P).bytes; }
 size_t gsr_image_bytes(int32_t width, int32_t height) { return ImageLayout(width, height).bytes; }
-size_t gsr_binning_bytes(uint32_t num_rendered, int32_t, int32_t) { return BinLayout(num_rendered).bytes; }
+size_t gsr_binning_bytes(uint32_t num_rendered, uint32_t num_visible, int32_t, int32_t, int32_t mode) {
+  return BinLayout(num_rendered, num_visible, mode).bytes;
+}
 size_t gsr_backward_bytes(int32_t P, uint32_t num_rendered) { return BwdLayout(P, num_rendered).bytes; }
 size_t gsr_sort_scratch_bytes(uint32_t n) { return SortLayout(n).bytes; }
 
-int gsr_forward_preprocess(const GsrParams* p, void* geom_ws, int32_t* radii, void* stream, uint32_t* num_rendered) {
+int gsr_forward_preprocess(const GsrParams* p, void* geom_ws, int32_t* radii, void* stream, uint32_t* num_rendered,
+                           uint32_t* num_visible) {
   if (int rc = validate(p)) return rc;
-  if (!num_rendered) return fail(GSR_E_BADARG, "num_rendered is NULL");
+  if (!num_rendered || !num_visible) return fail(GSR_E_BADARG, "num_rendered / num_visible is NULL");
   *num_rendered = 0;
+  *num_visible = 0;
   if (p->P == 0) return 0;
   if (!geom_ws || !radii) return fail(GSR_E_BADARG, "geom_ws / radii is NULL");
   if (((uintptr_t)geom_ws & 255u) != 0) return fail(GSR_E_ALIGN, "geom_ws must be 256-byte aligned");
@@ -133,22 +156,27 @@ int gsr_forward_preprocess(const GsrParams* p, void* geom_ws, int32_t* radii, vo
   {
     StageTimer t(p, GSR_STAGE_PREPROCESS_FWD, s);
     launch_preprocess_fwd(*p, at<GeomRec>(geom_ws, L.rec), at<BinInfo>(geom_ws, L.bin),
-                          at<uint32_t>(geom_ws, L.block_sums), radii, s);
+                          at<uint32_t>(geom_ws, L.block_sums), at<uint32_t>(geom_ws, L.block_vis), radii, s);
   }
   if (int rc = check(p, s, "preprocess_fwd")) return rc;
+  uint32_t* total = at<uint32_t>(geom_ws, L.total);
   {
     StageTimer t(p, GSR_STAGE_SCAN, s);
-    launch_scan_block_sums(at<uint32_t>(geom_ws, L.block_sums), at<uint32_t>(geom_ws, L.block_offs),
-                           at<uint32_t>(geom_ws, L.total), L.nblocks, s);
+    launch_scan_block_sums(at<uint32_t>(geom_ws, L.block_sums), at<uint32_t>(geom_ws, L.block_offs), total,
+                           at<uint32_t>(geom_ws, L.block_vis), at<uint32_t>(geom_ws, L.block_vis_offs), total + 1,
+                           L.nblocks, s);
   }
   if (int rc = check(p, s, "scan_block_sums")) return rc;
-  GSR_HIP(hipMemcpyAsync(num_rendered, at<uint32_t>(geom_ws, L.total), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  uint32_t host[2] = {0, 0};
+  GSR_HIP(hipMemcpyAsync(host, total, sizeof(host), hipMemcpyDeviceToHost, s));
   GSR_HIP(hipStreamSynchronize(s));
+  *num_rendered = host[0];
+  *num_visible = host[1];
   return 0;
 }
 
 int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t bin_ws_bytes, void* img_ws,
-                       uint32_t R, float* out_color, void* stream) {
+                       uint32_t R, uint32_t V, float* out_color, void* stream) {
   if (int rc = validate(p)) return rc;
   if (!img_ws || !out_color) return fail(GSR_E_BADARG, "img_ws / out_color is NULL");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -159,33 +187,79 @@ int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t b
   const GeomRec* rec = nullptr;
   if (p->P > 0 && R > 0) {
     if (!geom_ws || !bin_ws) return fail(GSR_E_BADARG, "geom_ws / bin_ws is NULL");
-    const BinLayout B(R);
-    if (bin_ws_bytes < B.bytes) return fail(GSR_E_CAPACITY, "binning workspace too small for num_rendered");
+    if (V == 0 || V > R || V > (uint32_t)p->P) return fail(GSR_E_BADARG, "num_visible inconsistent with num_rendered / P");
+    const int mode = p->binning_mode;
+    const BinLayout B(R, V, mode);
+    if (bin_ws_bytes < B.bytes) return fail(GSR_E_CAPACITY, "binning workspace too small for num_rendered / num_visible");
     if (((uintptr_t)bin_ws & 255u) != 0) return fail(GSR_E_ALIGN, "bin_ws must be 256-byte aligned");
     const GeomLayout L(p->P);
-    uint64_t* ka = at<uint64_t>(bin_ws, B.keys_a);
-    uint64_t* kb = at<uint64_t>(bin_ws, B.keys_b);
-    uint32_t* va = at<uint32_t>(bin_ws, B.vals_a);
-    uint32_t* vb = at<uint32_t>(bin_ws, B.vals_b);
     rec = at<GeomRec>(geom_ws, L.rec);
-    {
-      StageTimer t(p, GSR_STAGE_DUPLICATE, s);
-      launch_duplicate_with_keys(p->P, I.grid_x, at<BinInfo>(geom_ws, L.bin), at<uint32_t>(geom_ws, L.block_offs),
-                                 at<GeomRec>(geom_ws, L.rec), at<uint32_t>(geom_ws, L.offsets), ka, va, s);
-    }
-    if (int rc = check(p, s, "duplicate_with_keys")) return rc;
-    bool in_b;
-    {
-      StageTimer t(p, GSR_STAGE_SORT, s);
-      in_b = launch_sort_pairs(ka, va, kb, vb, R, 32 + tile_bits(I.tiles), at<char>(bin_ws, B.sort), s);
-    }
-    if (int rc = check(p, s, "sort_pairs")) return rc;
-    {
-      StageTimer t(p, GSR_STAGE_RANGES, s);
-      launch_identify_tile_ranges(R, in_b ? kb : ka, ranges, s);
+    const BinInfo* bin = at<BinInfo>(geom_ws, L.bin);
+    const int tb = tile_bits(I.tiles);
+    if (mode == GSR_BINNING_KEYS64) {
+      uint64_t* ka = at<uint64_t>(bin_ws, B.keys_a);
+      uint64_t* kb = at<uint64_t>(bin_ws, B.keys_b);
+      uint32_t* va = at<uint32_t>(bin_ws, B.vals_a);
+      uint32_t* vb = at<uint32_t>(bin_ws, B.vals_b);
+      {
+        StageTimer t(p, GSR_STAGE_DUPLICATE, s);
+        launch_duplicate_with_keys(p->P, I.grid_x, bin, at<uint32_t>(geom_ws, L.block_offs), at<GeomRec>(geom_ws, L.rec),
+                                   at<uint32_t>(geom_ws, L.offsets), ka, va, s);
+      }
+      if (int rc = check(p, s, "duplicate_with_keys")) return rc;
+      bool in_b;
+      {
+        StageTimer t(p, GSR_STAGE_SORT, s);
+        in_b = launch_sort_pairs(ka, va, kb, vb, R, 32 + tb, at<char>(bin_ws, B.sort), s);
+      }
+      if (int rc = check(p, s, "sort_pairs")) return rc;
+      {
+        StageTimer t(p, GSR_STAGE_RANGES, s);
+        launch_identify_tile_ranges(R, in_b ? kb : ka, ranges, s);
+      }
+      point_list = in_b ? vb : va;
+    } else {
+      uint32_t* dka = at<uint32_t>(bin_ws, B.dkey_a);
+      uint32_t* dkb = at<uint32_t>(bin_ws, B.dkey_b);
+      uint32_t* dia = at<uint32_t>(bin_ws, B.didx_a);
+      uint32_t* dib = at<uint32_t>(bin_ws, B.didx_b);
+      uint32_t* ita = at<uint32_t>(bin_ws, B.itile_a);
+      uint32_t* itb = at<uint32_t>(bin_ws, B.itile_b);
+      uint32_t* iga = at<uint32_t>(bin_ws, B.ig_a);
+      uint32_t* igb = at<uint32_t>(bin_ws, B.ig_b);
+      uint32_t* tiles_sorted = at<uint32_t>(bin_ws, B.tiles_sorted);
+      uint32_t* bsum2 = at<uint32_t>(bin_ws, B.bsum2);
+      uint32_t* boffs2 = at<uint32_t>(bin_ws, B.boffs2);
+      const uint32_t* didx_sorted;
+      {
+        StageTimer t(p, GSR_STAGE_SORT, s);     // depth sort of the visible Gaussians
+        launch_compact_visible(p->P, bin, at<uint32_t>(geom_ws, L.block_vis_offs), at<uint32_t>(geom_ws, L.block_offs),
+                               at<GeomRec>(geom_ws, L.rec), dka, dia, s);
+        const bool in_b = launch_sort_pairs_u32(dka, dia, dkb, dib, V, 32, at<char>(bin_ws, B.sort), s);
+        didx_sorted = in_b ? dib : dia;
+      }
+      if (int rc = check(p, s, "depth_sort")) return rc;
+      {
+        StageTimer t(p, GSR_STAGE_DUPLICATE, s);   // instances emitted in depth order
+        uint2* rect_sorted = at<uint2>(bin_ws, B.rect_sorted);
+        launch_gather_tiles(V, didx_sorted, bin, tiles_sorted, rect_sorted, bsum2, s);
+        launch_scan_block_sums(bsum2, boffs2, boffs2 + B.nblocks2 + 1, nullptr, nullptr, nullptr, (int)B.nblocks2, s);
+        launch_emit_instances(V, I.grid_x, didx_sorted, tiles_sorted, rect_sorted, boffs2, ita, iga, s);
+      }
+      if (int rc = check(p, s, "emit_instances")) return rc;
+      bool in_b;
+      {
+        StageTimer t(p, GSR_STAGE_SORT, s);     // stable partition by tile id
+        in_b = launch_sort_pairs_u32(ita, iga, itb, igb, R, tb, at<char>(bin_ws, B.sort), s);
+      }
+      if (int rc = check(p, s, "tile_sort")) return rc;
+      {
+        StageTimer t(p, GSR_STAGE_RANGES, s);
+        launch_identify_tile_ranges_u32(R, in_b ? itb : ita, ranges, s);
+      }
+      point_list = in_b ? igb : iga;
     }
     if (int rc = check(p, s, "identify_tile_ranges")) return rc;
-    point_list = in_b ? vb : va;
   }
   launch_build_tile_order(I.tiles, ranges, at<uint32_t>(img_ws, I.tile_order), s);
   {
@@ -198,8 +272,8 @@ int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t b
 }
 
 int gsr_backward(const GsrParams* p, const int32_t* radii, const void* geom_ws, const void* bin_ws, const void* img_ws,
-                 uint32_t R, const float* dL_dout_color, void* bwd_ws, size_t bwd_ws_bytes, const GsrGrads* grads,
-                 void* stream) {
+                 uint32_t R, uint32_t V, const float* dL_dout_color, void* bwd_ws, size_t bwd_ws_bytes,
+                 const GsrGrads* grads, void* stream) {
   if (int rc = validate(p)) return rc;
   if (!grads) return fail(GSR_E_BADARG, "grads is NULL");
   if (p->P == 0) return 0;
@@ -223,8 +297,7 @@ int gsr_backward(const GsrParams* p, const int32_t* radii, const void* geom_ws, 
   const GeomRec* rec = at<GeomRec>(geom_ws, L.rec);
   if (R > 0) {
     if (!bin_ws) return fail(GSR_E_BADARG, "bin_ws is NULL");
-    const BinLayout B(R);
-    const uint32_t* point_list = at<uint32_t>(bin_ws, sorted_in_b(p->width, p->height) ? B.vals_b : B.vals_a);
+    const uint32_t* point_list = sorted_views(bin_ws, R, V, p->width, p->height, p->binning_mode).point_list;
     GSR_HIP(hipMemsetAsync(flags, 0, R, s));
     {
       StageTimer t(p, GSR_STAGE_RENDER_BWD, s);
@@ -282,15 +355,15 @@ const char* gsr_stage_name(int32_t stage) {
 // stats[0] instances in all tile lists, [1] instances staged into LDS, [2] instances visited after the
 // sub-block cull, [3] sub-block evaluations, [4] evaluations with >= 1 contributing lane, [5] sum of tile_max.
 int gsr_debug_render_stats(const GsrParams* p, const void* geom_ws, const void* bin_ws, void* img_ws, uint32_t R,
-                           float* out_color, unsigned long long* stats /* device [8], zeroed by caller */, void* stream) {
+                           uint32_t V, float* out_color, unsigned long long* stats /* device [8], zeroed by caller */,
+                           void* stream) {
   if (int rc = validate(p)) return rc;
   if (!geom_ws || !bin_ws || !img_ws || !out_color || !stats || R == 0) return fail(GSR_E_BADARG, "NULL argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const ImageLayout I(p->width, p->height);
   const GeomLayout L(p->P);
-  const BinLayout B(R);
   launch_render_fwd(p->width, p->height, at<uint2>(img_ws, I.ranges),
-                    at<uint32_t>(bin_ws, sorted_in_b(p->width, p->height) ? B.vals_b : B.vals_a),
+                    sorted_views(bin_ws, R, V, p->width, p->height, p->binning_mode).point_list,
                     at<GeomRec>(geom_ws, L.rec), p->bg, out_color, at<float>(img_ws, I.final_T),
                     at<uint32_t>(img_ws, I.n_contrib), at<uint32_t>(img_ws, I.tile_max),
                     at<uint32_t>(img_ws, I.tile_order), at<uint32_t>(img_ws, I.queues), s, stats);
@@ -315,25 +388,27 @@ int gsr_debug_read_geom(const void* geom_ws, int32_t P, float* xy, float* conic_
   if (!geom_ws || P < 0) return fail(GSR_E_BADARG, "bad geom_ws / P");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const GeomLayout L(P);
-  launch_unpack_geom(P, at<GeomRec>(geom_ws, L.rec), at<BinInfo>(geom_ws, L.bin), at<uint32_t>(geom_ws, L.offsets), xy,
+  launch_unpack_geom(P, at<GeomRec>(geom_ws, L.rec), at<BinInfo>(geom_ws, L.bin), at<uint32_t>(geom_ws, L.block_offs), xy,
                      conic_opacity, rgb, depth, tiles_touched, point_offsets, rect, clamped, s);
   return check(nullptr, s, "unpack_geom");
 }
 
-int gsr_debug_read_binning(const void* bin_ws, uint32_t R, int32_t width, int32_t height, uint64_t* keys_sorted,
-                           uint32_t* point_list, void* stream) {
+int gsr_debug_read_binning(const void* geom_ws, int32_t P, const void* bin_ws, uint32_t R, uint32_t V, int32_t width,
+                           int32_t height, int32_t mode, uint64_t* keys_sorted, uint32_t* point_list, void* stream) {
   if (R == 0) return 0;
-  if (!bin_ws) return fail(GSR_E_BADARG, "bin_ws is NULL");
+  if (!bin_ws || !geom_ws) return fail(GSR_E_BADARG, "bin_ws / geom_ws is NULL");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const BinLayout B(R);
-  const bool in_b = sorted_in_b(width, height);
-  if (keys_sorted)
-    GSR_HIP(hipMemcpyAsync(keys_sorted, at<uint64_t>(bin_ws, in_b ? B.keys_b : B.keys_a), 8 * (size_t)R,
-                           hipMemcpyDeviceToDevice, s));
-  if (point_list)
-    GSR_HIP(hipMemcpyAsync(point_list, at<uint32_t>(bin_ws, in_b ? B.vals_b : B.vals_a), 4 * (size_t)R,
-                           hipMemcpyDeviceToDevice, s));
-  return 0;
+  const SortedViews v = sorted_views(bin_ws, R, V, width, height, mode);
+  if (keys_sorted) {
+    if (mode == GSR_BINNING_KEYS64) {
+      GSR_HIP(hipMemcpyAsync(keys_sorted, v.keys_sorted, 8 * (size_t)R, hipMemcpyDeviceToDevice, s));
+    } else {
+      const GeomLayout L(P);
+      launch_reconstruct_keys(R, v.tile_sorted, v.point_list, at<BinInfo>(geom_ws, L.bin), keys_sorted, s);
+    }
+  }
+  if (point_list) GSR_HIP(hipMemcpyAsync(point_list, v.point_list, 4 * (size_t)R, hipMemcpyDeviceToDevice, s));
+  return check(nullptr, s, "read_binning");
 }
 
 int gsr_debug_read_image(const void* img_ws, int32_t width, int32_t height, float* final_T, uint32_t* n_contrib,

@@ -53,7 +53,7 @@ constexpr int PRE_BLOCK = 256;      // Gaussians per preprocess / duplicate bloc
 
 // ---- workspace layouts (host + device agree through these helpers) -------------------------
 struct GeomLayout {
-  size_t rec, bin, offsets, block_sums, block_offs, total, bytes;
+  size_t rec, bin, offsets, block_sums, block_offs, block_vis, block_vis_offs, total, bytes;
   int nblocks;
   __host__ __device__ explicit GeomLayout(int P) {
     nblocks = (P + PRE_BLOCK - 1) / PRE_BLOCK;
@@ -63,7 +63,9 @@ struct GeomLayout {
     offsets = o;    o = align_up(o + 4 * (size_t)P, 256);
     block_sums = o; o = align_up(o + 4 * (size_t)(nblocks + 1), 256);
     block_offs = o; o = align_up(o + 4 * (size_t)(nblocks + 1), 256);
-    total = o;      o = align_up(o + 64, 256);
+    block_vis = o;  o = align_up(o + 4 * (size_t)(nblocks + 1), 256);        // visible Gaussians per block
+    block_vis_offs = o; o = align_up(o + 4 * (size_t)(nblocks + 1), 256);
+    total = o;      o = align_up(o + 64, 256);                               // [0] = R (instances), [1] = V (visible)
     bytes = o;
   }
 };
@@ -106,16 +108,44 @@ struct SortLayout {
   }
 };
 
+// Binning workspace.  mode 0 (default): two-level binning -- visible Gaussians are sorted by depth (u32 key),
+// instances are emitted in depth order and stably partitioned by tile id (u32 key); mode 1: upstream's layout,
+// one (u64 tile<<32|depth, u32 index) pair per instance sorted on 32 + tile bits.
 struct BinLayout {
-  size_t keys_a, keys_b, vals_a, vals_b, sort, bytes;
-  __host__ __device__ explicit BinLayout(uint32_t R) {
-    size_t n = R ? R : 1;
+  // mode 1
+  size_t keys_a, keys_b, vals_a, vals_b;
+  // mode 0
+  size_t dkey_a, dkey_b, didx_a, didx_b, tiles_sorted, rect_sorted, bsum2, boffs2, itile_a, itile_b, ig_a, ig_b;
+  size_t sort, bytes;
+  uint32_t nblocks2;
+  __host__ __device__ BinLayout(uint32_t R, uint32_t V, int mode) {
+    const size_t n = R ? R : 1, v = V ? V : 1;
+    nblocks2 = (uint32_t)((v + PRE_BLOCK - 1) / PRE_BLOCK);
     size_t o = 0;
-    keys_a = o; o = align_up(o + 8 * n, 256);
-    keys_b = o; o = align_up(o + 8 * n, 256);
-    vals_a = o; o = align_up(o + 4 * n, 256);
-    vals_b = o; o = align_up(o + 4 * n, 256);
-    sort = o;   o = align_up(o + SortLayout((uint32_t)n).bytes, 256);
+    keys_a = keys_b = vals_a = vals_b = 0;
+    dkey_a = dkey_b = didx_a = didx_b = tiles_sorted = rect_sorted = bsum2 = boffs2 = itile_a = itile_b = ig_a = ig_b = 0;
+    if (mode == 1) {
+      keys_a = o; o = align_up(o + 8 * n, 256);
+      keys_b = o; o = align_up(o + 8 * n, 256);
+      vals_a = o; o = align_up(o + 4 * n, 256);
+      vals_b = o; o = align_up(o + 4 * n, 256);
+      sort = o;   o = align_up(o + SortLayout((uint32_t)n).bytes, 256);
+    } else {
+      dkey_a = o; o = align_up(o + 4 * v, 256);
+      dkey_b = o; o = align_up(o + 4 * v, 256);
+      didx_a = o; o = align_up(o + 4 * v, 256);
+      didx_b = o; o = align_up(o + 4 * v, 256);
+      tiles_sorted = o; o = align_up(o + 4 * v, 256);
+      rect_sorted = o; o = align_up(o + 8 * v, 256);
+      bsum2 = o;  o = align_up(o + 4 * (size_t)(nblocks2 + 1), 256);
+      boffs2 = o; o = align_up(o + 4 * (size_t)(nblocks2 + 1) + 64, 256);
+      itile_a = o; o = align_up(o + 4 * n, 256);
+      itile_b = o; o = align_up(o + 4 * n, 256);
+      ig_a = o;   o = align_up(o + 4 * n, 256);
+      ig_b = o;   o = align_up(o + 4 * n, 256);
+      const size_t s1 = SortLayout((uint32_t)v).bytes, s2 = SortLayout((uint32_t)n).bytes;
+      sort = o;   o = align_up(o + (s1 > s2 ? s1 : s2), 256);
+    }
     bytes = o;
   }
 };

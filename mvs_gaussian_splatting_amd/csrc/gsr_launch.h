@@ -6,9 +6,11 @@
 namespace gsr {
 
 // preprocess.hip
-void launch_preprocess_fwd(const GsrParams& p, GeomRec* rec, BinInfo* bin, uint32_t* block_sums, int32_t* radii,
-                           hipStream_t s);
-void launch_scan_block_sums(const uint32_t* block_sums, uint32_t* block_offs, uint32_t* total, int nb, hipStream_t s);
+void launch_preprocess_fwd(const GsrParams& p, GeomRec* rec, BinInfo* bin, uint32_t* block_sums, uint32_t* block_vis,
+                           int32_t* radii, hipStream_t s);
+// exclusive scans of up to two per-block arrays in one launch (block 0: a, block 1: b); total_x = grand total
+void launch_scan_block_sums(const uint32_t* sums_a, uint32_t* offs_a, uint32_t* total_a, const uint32_t* sums_b,
+                            uint32_t* offs_b, uint32_t* total_b, int nb, hipStream_t s);
 void launch_preprocess_bwd(const GsrParams& p, const int32_t* radii, const GeomRec* rec, const GradRow* rows,
                            const uint8_t* row_flags, const GsrGrads& g, hipStream_t s);
 
@@ -18,9 +20,21 @@ void launch_duplicate_with_keys(int P, int grid_x, const BinInfo* bin, const uin
 // returns true when the sorted result ended in (keys_b, vals_b)
 bool launch_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, uint32_t n,
                        int end_bit, void* scratch, hipStream_t s);
+bool launch_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n,
+                           int end_bit, void* scratch, hipStream_t s);
+void launch_identify_tile_ranges_u32(uint32_t R, const uint32_t* tiles, uint2* ranges, hipStream_t s);
 inline int sort_passes(int end_bit) { return (end_bit + RADIX_BITS - 1) / RADIX_BITS; }
 void launch_identify_tile_ranges(uint32_t R, const uint64_t* keys, uint2* ranges, hipStream_t s);
 void launch_build_tile_order(int tiles, const uint2* ranges, uint32_t* order, hipStream_t s);
+void launch_compact_visible(int P, const BinInfo* bin, const uint32_t* block_vis_offs, const uint32_t* block_offs,
+                            GeomRec* rec, uint32_t* dkey, uint32_t* didx, hipStream_t s);
+void launch_gather_tiles(uint32_t V, const uint32_t* didx, const BinInfo* bin, uint32_t* tiles_sorted, uint2* rect_sorted,
+                         uint32_t* block_sums2, hipStream_t s);
+void launch_emit_instances(uint32_t V, int grid_x, const uint32_t* didx, const uint32_t* tiles_sorted,
+                           const uint2* rect_sorted, const uint32_t* block_offs2, uint32_t* inst_tile, uint32_t* inst_g,
+                           hipStream_t s);
+void launch_reconstruct_keys(uint32_t R, const uint32_t* tile_sorted, const uint32_t* point_list, const BinInfo* bin,
+                             uint64_t* keys, hipStream_t s);
 
 // render.hip
 void launch_render_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
@@ -37,7 +51,7 @@ void launch_l1_loss(const float* x, const float* gt, size_t n, float scale, floa
                     hipStream_t s);
 void launch_densify_stats(int P, const float* dL_dmeans2D, const int32_t* radii, float* accum, float* denom,
                           float* max_radii2D, hipStream_t s);
-void launch_unpack_geom(int P, const GeomRec* rec, const BinInfo* bin, const uint32_t* offsets, float* xy,
+void launch_unpack_geom(int P, const GeomRec* rec, const BinInfo* bin, const uint32_t* block_offs, float* xy,
                         float* conic_opacity, float* rgb, float* depth, uint32_t* tiles, uint32_t* point_offsets,
                         uint32_t* rect, uint32_t* clamped, hipStream_t s);
 

@@ -181,8 +181,10 @@ __device__ inline void wave_store_rows45(float* __restrict__ base, int first, in
 __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, GeomRec* __restrict__ rec,
                                                                    BinInfo* __restrict__ bin,
                                                                    uint32_t* __restrict__ block_sums,
+                                                                   uint32_t* __restrict__ block_vis,
                                                                    int32_t* __restrict__ radii) {
   __shared__ uint32_t wave_sums[PRE_BLOCK / WAVE];
+  __shared__ uint32_t wave_vis[PRE_BLOCK / WAVE];
   const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
   const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
   const int W = p.width, H = p.height;
@@ -320,22 +322,30 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
 
   // block total of tiles_touched -> first level of the hierarchical scan (§8 a5)
   const uint32_t ws = wave_reduce_add_u32(tiles);
-  if (lane == 0) wave_sums[wid] = ws;
+  const uint32_t wv = (uint32_t)__popcll(__ballot(vis));
+  if (lane == 0) { wave_sums[wid] = ws; wave_vis[wid] = wv; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t s = 0;
+    uint32_t s = 0, v = 0;
 #pragma unroll
-    for (int w = 0; w < PRE_BLOCK / WAVE; ++w) s += wave_sums[w];
+    for (int w = 0; w < PRE_BLOCK / WAVE; ++w) { s += wave_sums[w]; v += wave_vis[w]; }
     block_sums[blockIdx.x] = s;
+    block_vis[blockIdx.x] = v;
   }
 }
 
-// Exclusive scan of the per-block totals (single block); writes block_offs[nb] and total.
-__global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t* __restrict__ block_sums,
-                                                                uint32_t* __restrict__ block_offs,
-                                                                uint32_t* __restrict__ total, int nb) {
+// Exclusive scan of per-block totals; one block per array (blockIdx 0: a, 1: b); writes offs[nb] and the total.
+__global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t* __restrict__ sums_a,
+                                                                uint32_t* __restrict__ offs_a,
+                                                                uint32_t* __restrict__ total_a,
+                                                                const uint32_t* __restrict__ sums_b,
+                                                                uint32_t* __restrict__ offs_b,
+                                                                uint32_t* __restrict__ total_b, int nb) {
   __shared__ uint32_t wave_tot[1024 / WAVE];
   __shared__ uint32_t carry_s;
+  const uint32_t* __restrict__ block_sums = blockIdx.x == 0 ? sums_a : sums_b;
+  uint32_t* __restrict__ block_offs = blockIdx.x == 0 ? offs_a : offs_b;
+  uint32_t* __restrict__ total = blockIdx.x == 0 ? total_a : total_b;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
   if (tid == 0) carry_s = 0;
   __syncthreads();
@@ -709,13 +719,16 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(GsrParams p, 
 }
 
 
-void launch_preprocess_fwd(const GsrParams& p, GeomRec* rec, BinInfo* bin, uint32_t* block_sums, int32_t* radii,
-                           hipStream_t s) {
+void launch_preprocess_fwd(const GsrParams& p, GeomRec* rec, BinInfo* bin, uint32_t* block_sums, uint32_t* block_vis,
+                           int32_t* radii, hipStream_t s) {
   const int nb = (p.P + PRE_BLOCK - 1) / PRE_BLOCK;
-  if (nb > 0) hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, p, rec, bin, block_sums, radii);
+  if (nb > 0)
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, p, rec, bin, block_sums, block_vis, radii);
 }
-void launch_scan_block_sums(const uint32_t* block_sums, uint32_t* block_offs, uint32_t* total, int nb, hipStream_t s) {
-  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, block_offs, total, nb);
+void launch_scan_block_sums(const uint32_t* sums_a, uint32_t* offs_a, uint32_t* total_a, const uint32_t* sums_b,
+                            uint32_t* offs_b, uint32_t* total_b, int nb, hipStream_t s) {
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(sums_b ? 2 : 1), dim3(1024), 0, s, sums_a, offs_a, total_a, sums_b,
+                     offs_b, total_b, nb);
 }
 void launch_preprocess_bwd(const GsrParams& p, const int32_t* radii, const GeomRec* rec, const GradRow* rows,
                            const uint8_t* row_flags, const GsrGrads& g, hipStream_t s) {

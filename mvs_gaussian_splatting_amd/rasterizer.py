@@ -54,6 +54,12 @@ def _require_gpu(t: torch.Tensor) -> torch.device:
     return t.device
 
 
+def _binning_mode() -> int:
+    """GSR_BINNING=keys64 selects upstream's 64-bit (tile, depth) key sort; default is the two-level binning."""
+    import os
+    return _lib.BINNING_KEYS64 if os.environ.get("GSR_BINNING", "").lower() == "keys64" else _lib.BINNING_TWO_LEVEL
+
+
 def _stream(dev: torch.device) -> int:
     return torch.cuda.current_stream(dev).cuda_stream
 
@@ -84,6 +90,7 @@ def _make_params(dev, settings: GaussianRasterizationSettings, means3D, sh, colo
     p.profile = _lib.active_profile_handle()
     p.shs_rest = _ptr(sh_rest)
     p.act_flags = int(act_flags)
+    p.binning_mode = _binning_mode()
     return p, [bg, view, proj, campos]
 
 
@@ -113,15 +120,16 @@ class _RasterizeGaussians(torch.autograd.Function):
             img = torch.empty(lib.gsr_image_bytes(W, H), dtype=torch.uint8, device=dev)
             radii = torch.zeros(P, dtype=torch.int32, device=dev)
             color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
-            num_rendered = C.c_uint32(0)
+            num_rendered, num_visible = C.c_uint32(0), C.c_uint32(0)
             try:
                 _lib.check(lib.gsr_forward_preprocess(C.byref(params), geom.data_ptr(), _ptr(radii), stream,
-                                                      C.byref(num_rendered)), "gsr_forward_preprocess")
-                R = int(num_rendered.value)
-                nbytes = lib.gsr_binning_bytes(R, W, H)
+                                                      C.byref(num_rendered), C.byref(num_visible)),
+                           "gsr_forward_preprocess")
+                R, V = int(num_rendered.value), int(num_visible.value)
+                nbytes = lib.gsr_binning_bytes(R, V, W, H, params.binning_mode)
                 binning = torch.empty(nbytes, dtype=torch.uint8, device=dev)
                 _lib.check(lib.gsr_forward_render(C.byref(params), geom.data_ptr(), binning.data_ptr(), nbytes,
-                                                  img.data_ptr(), R, color.data_ptr(), stream), "gsr_forward_render")
+                                                  img.data_ptr(), R, V, color.data_ptr(), stream), "gsr_forward_render")
             except _lib.GsrError:
                 if raster_settings.debug:
                     torch.save((means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -132,6 +140,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = raster_settings
         ctx.profile = params.profile     # backward runs on an autograd thread: carry the handle explicitly
         ctx.num_rendered = R
+        ctx.num_visible = V
+        ctx.binning_mode = params.binning_mode
         ctx.keep = keep
         ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, geom,
                               binning, img)
@@ -153,6 +163,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             params, keep = _make_params(dev, settings, means3D, sh, colors_precomp, opacities, scales, rotations,
                                         cov3Ds_precomp)
             params.profile = ctx.profile
+            params.binning_mode = ctx.binning_mode
             stream = _stream(dev)
             new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
             g_means3D, g_means2D, g_opac = new(P, 3), new(P, 3), new(*opacities.shape)
@@ -167,7 +178,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             bwd_ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             try:
                 _lib.check(lib.gsr_backward(C.byref(params), _ptr(radii), geom.data_ptr(), binning.data_ptr(),
-                                            img.data_ptr(), R, grad_out_color.data_ptr(), bwd_ws.data_ptr(), nbytes,
+                                            img.data_ptr(), R, ctx.num_visible, grad_out_color.data_ptr(), bwd_ws.data_ptr(), nbytes,
                                             C.byref(grads), stream), "gsr_backward")
             except _lib.GsrError:
                 if settings.debug:
@@ -210,17 +221,19 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
             img = torch.empty(lib.gsr_image_bytes(W, H), dtype=torch.uint8, device=dev)
             radii = torch.zeros(P, dtype=torch.int32, device=dev)
             color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
-            num_rendered = C.c_uint32(0)
+            num_rendered, num_visible = C.c_uint32(0), C.c_uint32(0)
             _lib.check(lib.gsr_forward_preprocess(C.byref(params), geom.data_ptr(), _ptr(radii), stream,
-                                                  C.byref(num_rendered)), "gsr_forward_preprocess")
-            R = int(num_rendered.value)
-            nbytes = lib.gsr_binning_bytes(R, W, H)
+                                                  C.byref(num_rendered), C.byref(num_visible)), "gsr_forward_preprocess")
+            R, V = int(num_rendered.value), int(num_visible.value)
+            nbytes = lib.gsr_binning_bytes(R, V, W, H, params.binning_mode)
             binning = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             _lib.check(lib.gsr_forward_render(C.byref(params), geom.data_ptr(), binning.data_ptr(), nbytes,
-                                              img.data_ptr(), R, color.data_ptr(), stream), "gsr_forward_render")
+                                              img.data_ptr(), R, V, color.data_ptr(), stream), "gsr_forward_render")
         ctx.raster_settings = raster_settings
         ctx.profile = params.profile
         ctx.num_rendered = R
+        ctx.num_visible = V
+        ctx.binning_mode = params.binning_mode
         ctx.act_flags = flags
         ctx.keep = keep
         ctx.save_for_backward(means3D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations, radii, geom, binning, img)
@@ -241,6 +254,7 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
             params, keep = _make_params(dev, settings, means3D, f_dc, empty, raw_opacity, raw_scales, raw_rotations,
                                         empty, sh_rest=f_rest, act_flags=ctx.act_flags)
             params.profile = ctx.profile
+            params.binning_mode = ctx.binning_mode
             stream = _stream(dev)
             new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
             g_means3D, g_means2D = new(P, 3), new(P, 3)
@@ -251,7 +265,7 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
             nbytes = lib.gsr_backward_bytes(P, R)
             bwd_ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             _lib.check(lib.gsr_backward(C.byref(params), _ptr(radii), geom.data_ptr(), binning.data_ptr(),
-                                        img.data_ptr(), R, grad_out_color.data_ptr(), bwd_ws.data_ptr(), nbytes,
+                                        img.data_ptr(), R, ctx.num_visible, grad_out_color.data_ptr(), bwd_ws.data_ptr(), nbytes,
                                         C.byref(grads), stream), "gsr_backward")
         del keep
         return g_means3D, g_means2D, g_dc, g_rest, g_opac, g_scales, g_rot, None

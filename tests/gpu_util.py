@@ -18,7 +18,7 @@ def product_settings(cam, bg, sh_degree, dev, scale_modifier=1.0, debug=False):
 
 
 def forward_with_state(dev, settings, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                       cov3D_precomp=None):
+                       cov3D_precomp=None, binning_mode=None):
     """Forward through the C ABI keeping the workspaces; returns a dict of numpy/torch results."""
     lib = _lib.load()
     e = torch.empty(0, dtype=torch.float32, device=dev)
@@ -34,12 +34,15 @@ def forward_with_state(dev, settings, means3D, opacities, shs=None, colors_preco
         img = torch.empty(lib.gsr_image_bytes(W, H), dtype=torch.uint8, device=dev)
         radii = torch.zeros(P, dtype=torch.int32, device=dev)
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
-        R = C.c_uint32(0)
-        _lib.check(lib.gsr_forward_preprocess(C.byref(params), geom.data_ptr(), radii.data_ptr(), stream, C.byref(R)), "pre")
-        R = int(R.value)
-        nb = lib.gsr_binning_bytes(R, W, H)
+        R, V = C.c_uint32(0), C.c_uint32(0)
+        if binning_mode is not None:
+            params.binning_mode = binning_mode
+        _lib.check(lib.gsr_forward_preprocess(C.byref(params), geom.data_ptr(), radii.data_ptr(), stream, C.byref(R),
+                                              C.byref(V)), "pre")
+        R, V = int(R.value), int(V.value)
+        nb = lib.gsr_binning_bytes(R, V, W, H, params.binning_mode)
         binning = torch.empty(nb, dtype=torch.uint8, device=dev)
-        _lib.check(lib.gsr_forward_render(C.byref(params), geom.data_ptr(), binning.data_ptr(), nb, img.data_ptr(), R,
+        _lib.check(lib.gsr_forward_render(C.byref(params), geom.data_ptr(), binning.data_ptr(), nb, img.data_ptr(), R, V,
                                           color.data_ptr(), stream), "render")
         xy = torch.empty(P, 2, device=dev)
         con = torch.empty(P, 4, device=dev)
@@ -54,7 +57,8 @@ def forward_with_state(dev, settings, means3D, opacities, shs=None, colors_preco
                                            clamped.data_ptr(), stream), "read_geom")
         keys = torch.empty(max(R, 1), dtype=torch.int64, device=dev)
         plist = torch.empty(max(R, 1), dtype=torch.int32, device=dev)
-        _lib.check(lib.gsr_debug_read_binning(binning.data_ptr(), R, W, H, keys.data_ptr(), plist.data_ptr(), stream), "read_bin")
+        _lib.check(lib.gsr_debug_read_binning(geom.data_ptr(), P, binning.data_ptr(), R, V, W, H, params.binning_mode,
+                                              keys.data_ptr(), plist.data_ptr(), stream), "read_bin")
         gx, gy = (W + 15) // 16, (H + 15) // 16
         final_T = torch.empty(H, W, device=dev)
         n_contrib = torch.empty(H, W, dtype=torch.int32, device=dev)
@@ -63,7 +67,7 @@ def forward_with_state(dev, settings, means3D, opacities, shs=None, colors_preco
                                             ranges.data_ptr(), stream), "read_img")
         torch.cuda.synchronize(dev)
     del keep
-    return {"color": color.cpu(), "radii": radii.cpu(), "R": R, "xy": xy.cpu(), "conic_opacity": con.cpu(),
+    return {"color": color.cpu(), "radii": radii.cpu(), "R": R, "V": V, "xy": xy.cpu(), "conic_opacity": con.cpu(),
             "rgb": rgb.cpu(), "depth": depth.cpu(), "tiles": tiles.cpu().numpy().astype(np.int64),
             "offsets": offs.cpu().numpy().view(np.uint32), "rect": rect.cpu().numpy().astype(np.int64),
             "clamped": clamped.cpu().numpy(), "keys": keys[:R].cpu().numpy().view(np.uint64),

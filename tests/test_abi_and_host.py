@@ -40,7 +40,7 @@ def test_struct_layouts_match_the_c_compiler():
 #include "gsr.h"
 int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %d\n", sizeof(GsrParams), sizeof(GsrGrads), offsetof(GsrParams, means3D),
-         offsetof(GsrParams, bg), offsetof(GsrParams, profile), offsetof(GsrGrads, dL_dcov3D), GSR_STAGE_COUNT);
+         offsetof(GsrParams, bg), offsetof(GsrParams, binning_mode), offsetof(GsrGrads, dL_dshs_rest), GSR_STAGE_COUNT);
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -51,7 +51,7 @@ int main(void) {
         out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()
     vals = list(map(int, out))
     P, G = _lib.GsrParams, _lib.GsrGrads
-    assert vals == [C.sizeof(P), C.sizeof(G), P.means3D.offset, P.bg.offset, P.profile.offset, G.dL_dcov3D.offset,
+    assert vals == [C.sizeof(P), C.sizeof(G), P.means3D.offset, P.bg.offset, P.binning_mode.offset, G.dL_dshs_rest.offset,
                     _lib.STAGE_COUNT]
 
 
@@ -62,7 +62,8 @@ def test_workspace_sizes_are_monotone_and_aligned():
     assert lib.gsr_geom_bytes(1000) > 64 * 1000
     assert lib.gsr_geom_bytes(2000) > lib.gsr_geom_bytes(1000)
     assert lib.gsr_image_bytes(1920, 1080) >= 8 * 1920 * 1080
-    assert lib.gsr_binning_bytes(10_000_000, 1920, 1080) >= 24 * 10_000_000
+    assert lib.gsr_binning_bytes(10_000_000, 4_000_000, 1920, 1080, 1) >= 24 * 10_000_000
+    assert lib.gsr_binning_bytes(10_000_000, 4_000_000, 1920, 1080, 0) >= 16 * 10_000_000 + 28 * 4_000_000
     assert lib.gsr_backward_bytes(1000, 5000) >= 49 * 5000
     assert all(lib.gsr_stage_name(i) for i in range(_lib.STAGE_COUNT))
 
@@ -73,13 +74,13 @@ def test_bad_arguments_are_rejected_before_any_launch():
     p = _lib.GsrParams()
     p.P, p.width, p.height = 10, 64, 64
     n = C.c_uint32(0)
-    rc = lib.gsr_forward_preprocess(C.byref(p), None, None, None, C.byref(n))
+    rc = lib.gsr_forward_preprocess(C.byref(p), None, None, None, C.byref(n), C.byref(n))
     assert rc == -1 and b"non-NULL" in lib.gsr_last_error()
     with pytest.raises(_lib.GsrError):
         _lib.check(rc, "gsr_forward_preprocess")
-    assert lib.gsr_forward_preprocess(None, None, None, None, C.byref(n)) == -1
+    assert lib.gsr_forward_preprocess(None, None, None, None, C.byref(n), C.byref(n)) == -1
     p.width = 0
-    assert lib.gsr_forward_preprocess(C.byref(p), None, None, None, C.byref(n)) == -1
+    assert lib.gsr_forward_preprocess(C.byref(p), None, None, None, C.byref(n), C.byref(n)) == -1
 
 
 def _cpu_call(**over):

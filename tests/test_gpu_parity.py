@@ -30,16 +30,18 @@ def _oracle_forward(model, cam, bg, deg, dtype=torch.float32, **kw):
                          scales=c(model.get_scaling), rotations=c(model.get_rotation), want_aux=True, want_margin=True, **kw)
 
 
+@pytest.mark.parametrize("mode", [0, 1], ids=["two_level", "keys64"])
 @pytest.mark.parametrize("deg,P,w,h", [(3, 3000, 320, 176), (0, 2000, 200, 200), (1, 1500, 97, 131), (2, 800, 64, 48)])
-def test_forward_stages_match_oracle(gpu_device, deg, P, w, h):
+def test_forward_stages_match_oracle(gpu_device, deg, P, w, h, mode):
     from gpu_util import forward_with_state, product_settings
     model, cam, bg, _ = small_scene(P=P, sh_degree=deg, width=w, height=h)
     bg = torch.tensor([0.1, 0.2, 0.3])
     col, radii, aux = _oracle_forward(model, cam, bg, deg)
     st = product_settings(cam, bg, deg, gpu_device)
     out = forward_with_state(gpu_device, st, model.get_xyz, model.get_opacity, shs=model.get_features,
-                             scales=model.get_scaling, rotations=model.get_rotation)
+                             scales=model.get_scaling, rotations=model.get_rotation, binning_mode=mode)
     pre = aux["pre"]
+    assert out["V"] == int((radii > 0).sum())
     # ---- preprocess: integers exact ------------------------------------------------------
     assert torch.equal(out["radii"], radii)
     assert np.array_equal(out["tiles"], pre["tiles_touched"].numpy())

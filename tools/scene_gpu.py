@@ -39,15 +39,15 @@ class GpuScene:
 
     def forward(self):
         lib = self.lib
-        R = C.c_uint32(0)
+        R, V = C.c_uint32(0), C.c_uint32(0)
         _lib.check(lib.gsr_forward_preprocess(C.byref(self.params), self.geom.data_ptr(), self.radii.data_ptr(),
-                                              self.stream, C.byref(R)), "pre")
-        self.R = R.value
-        nb = lib.gsr_binning_bytes(self.R, self.W, self.H)
+                                              self.stream, C.byref(R), C.byref(V)), "pre")
+        self.R, self.V = R.value, V.value
+        nb = lib.gsr_binning_bytes(self.R, self.V, self.W, self.H, self.params.binning_mode)
         if self.binning is None or self.binning.numel() < nb:
             self.binning = torch.empty(nb, dtype=torch.uint8, device=self.dev)
         _lib.check(lib.gsr_forward_render(C.byref(self.params), self.geom.data_ptr(), self.binning.data_ptr(),
-                                          self.binning.numel(), self.img.data_ptr(), self.R, self.color.data_ptr(),
+                                          self.binning.numel(), self.img.data_ptr(), self.R, self.V, self.color.data_ptr(),
                                           self.stream), "render")
 
     def backward(self, dL_dpix):
@@ -56,10 +56,10 @@ class GpuScene:
             new = lambda *s: torch.empty(*s, device=dev)  # noqa: E731
             self.g = [new(P, 3), new(P, 3), new(P, 16, 3), new(P, 1), new(P, 3), new(P, 4)]
             self.grads = _lib.GsrGrads(self.g[0].data_ptr(), self.g[1].data_ptr(), self.g[2].data_ptr(), None,
-                                       self.g[3].data_ptr(), self.g[4].data_ptr(), self.g[5].data_ptr(), None)
+                                       self.g[3].data_ptr(), self.g[4].data_ptr(), self.g[5].data_ptr(), None, None)
         nb = lib.gsr_backward_bytes(P, self.R)
         if not hasattr(self, "bwd_ws") or self.bwd_ws.numel() < nb:
             self.bwd_ws = torch.empty(nb, dtype=torch.uint8, device=dev)
         _lib.check(lib.gsr_backward(C.byref(self.params), self.radii.data_ptr(), self.geom.data_ptr(),
-                                    self.binning.data_ptr(), self.img.data_ptr(), self.R, dL_dpix.data_ptr(),
+                                    self.binning.data_ptr(), self.img.data_ptr(), self.R, self.V, dL_dpix.data_ptr(),
                                     self.bwd_ws.data_ptr(), self.bwd_ws.numel(), C.byref(self.grads), self.stream), "bwd")
