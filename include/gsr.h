@@ -174,6 +174,13 @@ const char* gsr_stage_name(int32_t stage);
  * loss_sum[0] += sum|x-gt| (caller zero-fills, divides by n), dL_dx = sign(x-gt) * scale. */
 int gsr_l1_loss_fwd_bwd(const float* x, const float* gt, size_t n, float scale, float* loss_sum,
                         float* dL_dx, void* stream);
+/* The reference's training loss (train.py:99-101) in two kernels: (1-lambda)*L1 + lambda*(1 - SSIM) with SSIM as
+ * utils/loss_utils.py:23-63 (11x11 Gaussian window, sigma 1.5, zero padding, mean over C*H*W).
+ * sums[0] += sum|x-gt|, sums[1] += sum SSIM (caller zero-fills; loss = (1-lambda)*sums[0]/n + lambda*(1 - sums[1]/n));
+ * dL_dx receives the full gradient of that loss; workspace = 3*C*H*W floats (gsr_l1_dssim_workspace_bytes). */
+size_t gsr_l1_dssim_workspace_bytes(int32_t C, int32_t H, int32_t W);
+int gsr_l1_dssim_loss_fwd_bwd(const float* x, const float* gt, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+                              float* sums, float* dL_dx, void* workspace, void* stream);
 /* scene/gaussian_model.py:775-777 + train.py:130 fused: for radii>0:
  * xyz_gradient_accum += ||dL_dmeans2D.xy||, denom += 1, max_radii2D = max(max_radii2D, radii) */
 int gsr_densify_stats(int32_t P, const float* dL_dmeans2D /*[P,3]*/, const int32_t* radii,

@@ -432,6 +432,18 @@ int gsr_l1_loss_fwd_bwd(const float* x, const float* gt, size_t n, float scale, 
   return check(nullptr, s, "l1_loss");
 }
 
+size_t gsr_l1_dssim_workspace_bytes(int32_t C, int32_t H, int32_t W) {
+  return (C <= 0 || H <= 0 || W <= 0) ? 0 : 3 * sizeof(float) * (size_t)C * (size_t)H * (size_t)W;
+}
+int gsr_l1_dssim_loss_fwd_bwd(const float* x, const float* gt, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+                              float* sums, float* dL_dx, void* workspace, void* stream) {
+  if (!x || !gt || !sums || !dL_dx || !workspace) return fail(GSR_E_BADARG, "NULL argument");
+  if (C <= 0 || H <= 0 || W <= 0 || C > 65535) return fail(GSR_E_BADARG, "bad image shape");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  launch_l1_dssim(x, gt, C, H, W, lambda_dssim, sums, dL_dx, static_cast<float*>(workspace), s);
+  return check(nullptr, s, "l1_dssim");
+}
+
 int gsr_densify_stats(int32_t P, const float* dL_dmeans2D, const int32_t* radii, float* xyz_gradient_accum, float* denom,
                       float* max_radii2D, void* stream) {
   if (P < 0) return fail(GSR_E_BADARG, "P < 0");

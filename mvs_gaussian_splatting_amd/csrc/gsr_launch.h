@@ -46,6 +46,10 @@ void launch_render_bwd(int W, int H, const uint2* ranges, const uint32_t* point_
                        const float* dL_dpix, GradRow* rows, uint8_t* row_flags, const uint32_t* tile_order,
                        uint32_t* queue, hipStream_t s);
 
+// loss.hip
+void launch_l1_dssim(const float* x, const float* gt, int C, int H, int W, float lambda, float* sums, float* dL_dx,
+                     float* maps, hipStream_t s);
+
 // aux.hip
 void launch_l1_loss(const float* x, const float* gt, size_t n, float scale, float* loss_sum, float* dL_dx,
                     hipStream_t s);

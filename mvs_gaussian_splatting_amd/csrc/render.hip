@@ -447,7 +447,7 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, floa
   }
 }
 
-__global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) void render_bwd_kernel(int W, int H, int grid_x, int num_tiles,
+__global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE, 6) void render_bwd_kernel(int W, int H, int grid_x, int num_tiles,
                                                           const uint32_t* __restrict__ tile_order,
                                                           const uint2* __restrict__ ranges,
                                                           const uint32_t* __restrict__ point_list,

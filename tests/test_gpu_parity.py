@@ -368,3 +368,46 @@ def test_full_size_train_step_is_deterministic_and_fused_matches_getters(gpu_dev
     for a, b in zip(g1, g3):
         assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-12
     assert all(torch.isfinite(a).all() for a in g1)
+
+
+def test_l1_and_dssim_loss_match_reference_golden(gpu_device):
+    """fused L1 and L1 + D-SSIM kernels against the fixtures generated from the reference's
+    utils/loss_utils.py (value and gradient), and against torch on a 1080p-shaped input."""
+    import os
+    from mvs_gaussian_splatting_amd import l1_loss, l1_dssim_loss
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loss.npz"))
+    dev = gpu_device
+    a = torch.tensor(g["a"], device=dev, requires_grad=True)
+    b = torch.tensor(g["b"], device=dev)
+    l = l1_loss(a, b)
+    l.backward()
+    assert math.isclose(l.item(), float(g["l1"]), rel_tol=1e-6)
+    assert torch.allclose(a.grad.cpu(), torch.tensor(g["l1_grad"]))
+    lam = 0.2
+    a.grad = None
+    tot = l1_dssim_loss(a, b, lam)
+    tot.backward()
+    want = (1 - lam) * float(g["l1"]) + lam * (1 - float(g["ssim"]))
+    assert math.isclose(tot.item(), want, rel_tol=1e-5)
+    want_grad = (1 - lam) * torch.tensor(g["l1_grad"]) - lam * torch.tensor(g["ssim_grad"])
+    err = float((a.grad.cpu() - want_grad).abs().max()) / float(want_grad.abs().max())
+    assert err <= 1e-4, err
+    # odd, non-multiple-of-16 shape vs a torch restatement on the device
+    x = torch.rand(3, 131, 77, device=dev, requires_grad=True)
+    y = torch.rand(3, 131, 77, device=dev)
+    l1_dssim_loss(x, y, lam).backward()
+    gx = x.grad.clone(); x.grad = None
+    import torch.nn.functional as F
+    w1 = torch.tensor([math.exp(-(i - 5) ** 2 / (2 * 1.5 ** 2)) for i in range(11)], device=dev)
+    w1 = (w1 / w1.sum()).unsqueeze(1)
+    win = (w1 @ w1.t()).expand(3, 1, 11, 11).contiguous()
+    def ssim_t(p, q):
+        p, q = p[None], q[None]
+        m1, m2 = F.conv2d(p, win, padding=5, groups=3), F.conv2d(q, win, padding=5, groups=3)
+        s1 = F.conv2d(p * p, win, padding=5, groups=3) - m1 * m1
+        s2 = F.conv2d(q * q, win, padding=5, groups=3) - m2 * m2
+        s12 = F.conv2d(p * q, win, padding=5, groups=3) - m1 * m2
+        return (((2 * m1 * m2 + 1e-4) * (2 * s12 + 9e-4)) / ((m1 * m1 + m2 * m2 + 1e-4) * (s1 + s2 + 9e-4))).mean()
+    ref = (1 - lam) * (x - y).abs().mean() + lam * (1 - ssim_t(x, y))
+    ref.backward()
+    assert float((gx - x.grad).abs().max()) <= 1e-4 * float(x.grad.abs().max())
