@@ -132,6 +132,10 @@ int gsr_backward(const GsrParams* p, const int32_t* radii, const void* geom_ws, 
                  const float* dL_dout_color /* [3,H,W] */,
                  void* bwd_ws, size_t bwd_ws_bytes, const GsrGrads* grads, void* stream);
 
+/* `_C.mark_visible(means3D, viewmatrix, projmatrix)` of the upstream module (unused by the reference): visible[i] = 1
+ * when Gaussian i passes the near-plane test of the preprocess stage (view z > 0.2). */
+int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* visible, void* stream);
+
 /* ---- unit entry points (each stage callable on its own; used by the parity tests) ------- */
 /* keys_out/vals_out receive the result; *_tmp are scratch of the same size; bits sorted: [0,end_bit) */
 size_t gsr_sort_scratch_bytes(uint32_t n);

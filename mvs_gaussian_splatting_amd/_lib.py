@@ -55,6 +55,7 @@ SYMBOLS = {
                                      C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "gsr_backward": (C.c_int, [C.POINTER(GsrParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(GsrGrads), C.c_void_p]),
+    "gsr_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsr_sort_scratch_bytes": (C.c_size_t, [C.c_uint32]),
     "gsr_sort_pairs_u64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32,
                                      C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),

@@ -54,6 +54,18 @@ __global__ __launch_bounds__(256) void densify_stats_kernel(int P, const float* 
   }
 }
 
+// markVisible of the upstream module (unused by the reference, kept for API completeness): the near-plane test of
+// the preprocess stage, view z > 0.2.
+__global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* __restrict__ means3D,
+                                                           const float* __restrict__ viewmatrix,
+                                                           uint8_t* __restrict__ visible) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const float x = means3D[3 * (size_t)i], y = means3D[3 * (size_t)i + 1], z = means3D[3 * (size_t)i + 2];
+  const float vz = viewmatrix[2] * x + viewmatrix[6] * y + viewmatrix[10] * z + viewmatrix[14];
+  visible[i] = vz > NEAR_Z ? 1 : 0;
+}
+
 __global__ __launch_bounds__(PRE_BLOCK) void unpack_geom_kernel(int P, const GeomRec* __restrict__ rec,
                                                                 const BinInfo* __restrict__ bin,
                                                                 const uint32_t* __restrict__ block_offs, float* xy,
@@ -106,6 +118,10 @@ void launch_densify_stats(int P, const float* dL_dmeans2D, const int32_t* radii,
   if (P <= 0) return;
   hipLaunchKernelGGL(densify_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, dL_dmeans2D, radii, accum, denom,
                      max_radii2D);
+}
+void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* visible, hipStream_t s) {
+  if (P <= 0) return;
+  hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, viewmatrix, visible);
 }
 void launch_unpack_geom(int P, const GeomRec* rec, const BinInfo* bin, const uint32_t* block_offs, float* xy,
                         float* conic_opacity, float* rgb, float* depth, uint32_t* tiles, uint32_t* point_offsets,

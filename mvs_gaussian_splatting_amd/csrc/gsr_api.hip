@@ -370,6 +370,15 @@ int gsr_debug_render_stats(const GsrParams* p, const void* geom_ws, const void* 
   return check(p, s, "render_stats");
 }
 
+int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* visible, void* stream) {
+  if (P < 0) return fail(GSR_E_BADARG, "P < 0");
+  if (P == 0) return 0;
+  if (!means3D || !viewmatrix || !visible) return fail(GSR_E_BADARG, "NULL argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  launch_mark_visible(P, means3D, viewmatrix, visible, s);
+  return check(nullptr, s, "mark_visible");
+}
+
 int gsr_sort_pairs_u64(uint64_t* keys, uint32_t* vals, uint64_t* keys_tmp, uint32_t* vals_tmp, uint32_t n,
                        int32_t end_bit, void* scratch, void* stream, int32_t* result_in_tmp) {
   if (!result_in_tmp) return fail(GSR_E_BADARG, "result_in_tmp is NULL");

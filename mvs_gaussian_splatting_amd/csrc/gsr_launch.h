@@ -55,6 +55,7 @@ void launch_l1_loss(const float* x, const float* gt, size_t n, float scale, floa
                     hipStream_t s);
 void launch_densify_stats(int P, const float* dL_dmeans2D, const int32_t* radii, float* accum, float* denom,
                           float* max_radii2D, hipStream_t s);
+void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* visible, hipStream_t s);
 void launch_unpack_geom(int P, const GeomRec* rec, const BinInfo* bin, const uint32_t* block_offs, float* xy,
                         float* conic_opacity, float* rgb, float* depth, uint32_t* tiles, uint32_t* point_offsets,
                         uint32_t* rect, uint32_t* clamped, hipStream_t s);

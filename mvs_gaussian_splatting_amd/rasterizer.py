@@ -290,6 +290,18 @@ class GaussianRasterizer(nn.Module):
         super().__init__()
         self.raster_settings = raster_settings
 
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """Frustum (near-plane) visibility of the upstream module's ``markVisible``; bool ``[P]``."""
+        lib = _lib.load()
+        dev = _require_gpu(positions)
+        with torch.no_grad(), torch.cuda.device(dev):
+            pos = _f32c(positions, "positions", dev)
+            view = _f32c(self.raster_settings.viewmatrix, "viewmatrix", dev)
+            vis = torch.empty(pos.shape[0], dtype=torch.uint8, device=dev)
+            _lib.check(lib.gsr_mark_visible(int(pos.shape[0]), _ptr(pos), view.data_ptr(), _ptr(vis), _stream(dev)),
+                       "gsr_mark_visible")
+        return vis.bool()
+
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None):
         raster_settings = self.raster_settings

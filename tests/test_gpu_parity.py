@@ -411,3 +411,14 @@ def test_l1_and_dssim_loss_match_reference_golden(gpu_device):
     ref = (1 - lam) * (x - y).abs().mean() + lam * (1 - ssim_t(x, y))
     ref.backward()
     assert float((gx - x.grad).abs().max()) <= 1e-4 * float(x.grad.abs().max())
+
+
+def test_mark_visible_matches_preprocess_near_plane(gpu_device):
+    from mvs_gaussian_splatting_amd import GaussianRasterizer
+    from gpu_util import product_settings
+    model, cam, bg, _ = small_scene(P=4000, sh_degree=0, width=64, height=64, view=3)
+    st = product_settings(cam, bg, 0, gpu_device)
+    vis = GaussianRasterizer(st).markVisible(model.get_xyz.to(gpu_device)).cpu()
+    z = model.get_xyz @ cam.world_view_transform[:3, 2] + cam.world_view_transform[3, 2]
+    robust = (z - 0.2).abs() > 1e-5
+    assert torch.equal(vis[robust], (z > 0.2)[robust]) and 0 < int(vis.sum()) < 4000
