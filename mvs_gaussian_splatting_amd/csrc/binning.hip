@@ -18,7 +18,7 @@ constexpr uint32_t DUP_SMALL = 16;
 __global__ __launch_bounds__(PRE_BLOCK) void duplicate_with_keys_kernel(int P, int grid_x,
                                                                         const BinInfo* __restrict__ bin,
                                                                         const uint32_t* __restrict__ block_offs,
-                                                                        GeomRec* __restrict__ rec,
+                                                                        uint32_t* __restrict__ slot_base,
                                                                         uint32_t* __restrict__ point_offsets,
                                                                         uint64_t* __restrict__ keys,
                                                                         uint32_t* __restrict__ vals) {
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void duplicate_with_keys_kernel(int P, i
   const uint32_t off = base + inc - bi.tiles;   // exclusive
   if (idx < P) {
     point_offsets[idx] = off + bi.tiles;        // inclusive scan, as upstream's point_offsets
-    if (bi.tiles) rec[idx].offs_excl = off;
+    slot_base[idx] = off;
   }
   const uint32_t x0 = bi.rect_min & 0xffffu, y0 = bi.rect_min >> 16;
   const uint32_t w = bi.rect_wh & 0xffffu;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void duplicate_with_keys_kernel(int P, i
 __global__ __launch_bounds__(PRE_BLOCK) void compact_visible_kernel(int P, const BinInfo* __restrict__ bin,
                                                                     const uint32_t* __restrict__ block_vis_offs,
                                                                     const uint32_t* __restrict__ block_offs,
-                                                                    GeomRec* __restrict__ rec,
+                                                                    uint32_t* __restrict__ slot_base,
                                                                     uint32_t* __restrict__ dkey,
                                                                     uint32_t* __restrict__ didx) {
   __shared__ uint32_t wave_tot[PRE_BLOCK / WAVE];
@@ -110,10 +110,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void compact_visible_kernel(int P, const
     const uint32_t o = base + inc - 1u;
     dkey[o] = __float_as_uint(bi.depth);
     didx[o] = (uint32_t)idx;
-    // slot range of this Gaussian's per-instance gradient rows: index-major (any bijection works; this one is
-    // written with neighbouring lanes touching neighbouring records)
-    rec[idx].offs_excl = tbase + tinc - bi.tiles;
   }
+  // slot range of this Gaussian's per-instance gradient rows: index-major (any bijection works), coalesced write
+  if (idx < P) slot_base[idx] = tbase + tinc - bi.tiles;
 }
 
 __global__ __launch_bounds__(PRE_BLOCK) void gather_tiles_kernel(uint32_t V, const uint32_t* __restrict__ didx,
@@ -141,6 +140,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void gather_tiles_kernel(uint32_t V, con
   }
 }
 
+// Load-balanced expansion: the block's 256 Gaussians own a contiguous run of `total` instances; every lane
+// takes output slots (not Gaussians), finds the owning Gaussian by binary search in the block's inclusive scan
+// (LDS) and derives the tile from the slot's rank inside the rect -- fully coalesced stores, no divergence on
+// the splat size (a per-Gaussian loop here ran at 0.5 TB/s).
 __global__ __launch_bounds__(PRE_BLOCK) void emit_instances_kernel(uint32_t V, int grid_x,
                                                                    const uint32_t* __restrict__ didx,
                                                                    const uint32_t* __restrict__ tiles_sorted,
@@ -149,51 +152,50 @@ __global__ __launch_bounds__(PRE_BLOCK) void emit_instances_kernel(uint32_t V, i
                                                                    uint32_t* __restrict__ inst_tile,
                                                                    uint32_t* __restrict__ inst_g) {
   __shared__ uint32_t wave_tot[PRE_BLOCK / WAVE];
+  __shared__ uint32_t s_incl[PRE_BLOCK];      // inclusive scan of tiles within the block
+  __shared__ uint32_t s_g[PRE_BLOCK];
+  __shared__ uint32_t s_min[PRE_BLOCK];       // rect min: x | y << 16
+  __shared__ uint32_t s_w[PRE_BLOCK];         // rect width
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
   const uint32_t i = blockIdx.x * PRE_BLOCK + tid;
   uint32_t g = 0, tiles = 0;
-  BinInfo bi{0u, 0u, 0.0f, 0u};
+  uint2 rr = make_uint2(0u, 1u);
   if (i < V) {
     g = didx[i];
     tiles = tiles_sorted[i];
-    const uint2 rr = rect_sorted[i];
-    bi.rect_min = rr.x;
-    bi.rect_wh = rr.y;
+    rr = rect_sorted[i];
   }
   const uint32_t inc = wave_incl_scan_u32(tiles);
   if (lane == WAVE - 1) wave_tot[wid] = inc;
   __syncthreads();
-  uint32_t base = block_offs2[blockIdx.x];
+  uint32_t wbase = 0;
 #pragma unroll
   for (int w = 0; w < PRE_BLOCK / WAVE; ++w)
-    if (w < wid) base += wave_tot[w];
-  const uint32_t off = base + inc - tiles;   // first instance of this Gaussian in the depth-ordered array
-  const uint32_t x0 = bi.rect_min & 0xffffu, y0 = bi.rect_min >> 16;
-  const uint32_t w = bi.rect_wh & 0xffffu;
-  if (tiles && tiles <= DUP_SMALL) {
-    uint32_t o = off;
-    const uint32_t h = bi.rect_wh >> 16;
-    for (uint32_t y = y0; y < y0 + h; ++y)
-      for (uint32_t x = x0; x < x0 + w; ++x) {
-        inst_tile[o] = y * (uint32_t)grid_x + x;
-        inst_g[o] = g;
-        ++o;
-      }
-  }
-  unsigned long long big = __ballot(tiles > DUP_SMALL);   // large splats: the whole wave emits
-  while (big) {
-    const int src = __ffsll((long long)big) - 1;
-    big &= big - 1;
-    const uint32_t s_tiles = __shfl(tiles, src, WAVE);
-    const uint32_t s_off = __shfl(off, src, WAVE);
-    const uint32_t s_min = __shfl(bi.rect_min, src, WAVE);
-    const uint32_t s_w = __shfl(w, src, WAVE);
-    const uint32_t s_g = __shfl(g, src, WAVE);
-    const uint32_t sx0 = s_min & 0xffffu, sy0 = s_min >> 16;
-    for (uint32_t k = (uint32_t)lane; k < s_tiles; k += WAVE) {
-      inst_tile[s_off + k] = (sy0 + k / s_w) * (uint32_t)grid_x + (sx0 + k % s_w);
-      inst_g[s_off + k] = s_g;
+    if (w < wid) wbase += wave_tot[w];
+  s_incl[tid] = wbase + inc;
+  s_g[tid] = g;
+  s_min[tid] = rr.x;
+  s_w[tid] = max(rr.y & 0xffffu, 1u);
+  __syncthreads();
+  const uint32_t total = s_incl[PRE_BLOCK - 1];
+  const uint32_t base = block_offs2[blockIdx.x];
+  for (uint32_t o = (uint32_t)tid; o < total; o += PRE_BLOCK) {
+    // smallest j with s_incl[j] > o
+    int lo = 0, hi = PRE_BLOCK - 1;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int mid = (lo + hi) >> 1;
+      if (s_incl[mid] > o) hi = mid; else lo = mid + 1;
     }
+    const int j = lo;
+    const uint32_t first = j ? s_incl[j - 1] : 0u;
+    const uint32_t k = o - first;                    // rank of the tile inside the rect (y outer, x inner)
+    const uint32_t w = s_w[j];
+    uint32_t q = (uint32_t)(((float)k + 0.5f) * (1.0f / (float)w));   // k / w (exact for k < 2^20)
+    const uint32_t mn = s_min[j];
+    const uint32_t x = (mn & 0xffffu) + (k - q * w), y = (mn >> 16) + q;
+    inst_tile[base + o] = y * (uint32_t)grid_x + x;
+    inst_g[base + o] = s_g[j];
   }
 }
 
@@ -478,11 +480,11 @@ __global__ __launch_bounds__(1024) void build_tile_order_kernel(int tiles, const
   }
 }
 
-void launch_duplicate_with_keys(int P, int grid_x, const BinInfo* bin, const uint32_t* block_offs, GeomRec* rec,
+void launch_duplicate_with_keys(int P, int grid_x, const BinInfo* bin, const uint32_t* block_offs, uint32_t* slot_base,
                                 uint32_t* point_offsets, uint64_t* keys, uint32_t* vals, hipStream_t s) {
   const int nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
   if (nb > 0)
-    hipLaunchKernelGGL(duplicate_with_keys_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, P, grid_x, bin, block_offs, rec,
+    hipLaunchKernelGGL(duplicate_with_keys_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, P, grid_x, bin, block_offs, slot_base,
                        point_offsets, keys, vals);
 }
 
@@ -519,10 +521,10 @@ bool launch_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b,
 }
 
 void launch_compact_visible(int P, const BinInfo* bin, const uint32_t* block_vis_offs, const uint32_t* block_offs,
-                            GeomRec* rec, uint32_t* dkey, uint32_t* didx, hipStream_t s) {
+                            uint32_t* slot_base, uint32_t* dkey, uint32_t* didx, hipStream_t s) {
   const int nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
   if (nb > 0)
-    hipLaunchKernelGGL(compact_visible_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, P, bin, block_vis_offs, block_offs, rec,
+    hipLaunchKernelGGL(compact_visible_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, P, bin, block_vis_offs, block_offs, slot_base,
                        dkey, didx);
 }
 void launch_gather_tiles(uint32_t V, const uint32_t* didx, const BinInfo* bin, uint32_t* tiles_sorted, uint2* rect_sorted,

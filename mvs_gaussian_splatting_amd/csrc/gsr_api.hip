@@ -203,8 +203,8 @@ int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t b
       uint32_t* vb = at<uint32_t>(bin_ws, B.vals_b);
       {
         StageTimer t(p, GSR_STAGE_DUPLICATE, s);
-        launch_duplicate_with_keys(p->P, I.grid_x, bin, at<uint32_t>(geom_ws, L.block_offs), at<GeomRec>(geom_ws, L.rec),
-                                   at<uint32_t>(geom_ws, L.offsets), ka, va, s);
+        launch_duplicate_with_keys(p->P, I.grid_x, bin, at<uint32_t>(geom_ws, L.block_offs),
+                                   at<uint32_t>(geom_ws, L.slot_base), at<uint32_t>(geom_ws, L.offsets), ka, va, s);
       }
       if (int rc = check(p, s, "duplicate_with_keys")) return rc;
       bool in_b;
@@ -234,7 +234,7 @@ int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t b
       {
         StageTimer t(p, GSR_STAGE_SORT, s);     // depth sort of the visible Gaussians
         launch_compact_visible(p->P, bin, at<uint32_t>(geom_ws, L.block_vis_offs), at<uint32_t>(geom_ws, L.block_offs),
-                               at<GeomRec>(geom_ws, L.rec), dka, dia, s);
+                               at<uint32_t>(geom_ws, L.slot_base), dka, dia, s);
         const bool in_b = launch_sort_pairs_u32(dka, dia, dkb, dib, V, 32, at<char>(bin_ws, B.sort), s);
         didx_sorted = in_b ? dib : dia;
       }
@@ -301,7 +301,8 @@ int gsr_backward(const GsrParams* p, const int32_t* radii, const void* geom_ws, 
     GSR_HIP(hipMemsetAsync(flags, 0, R, s));
     {
       StageTimer t(p, GSR_STAGE_RENDER_BWD, s);
-      launch_render_bwd(p->width, p->height, at<uint2>(img_ws, I.ranges), point_list, rec, p->bg,
+      launch_render_bwd(p->width, p->height, at<uint2>(img_ws, I.ranges), point_list, rec,
+                        at<uint32_t>(geom_ws, L.slot_base), p->bg,
                         at<float>(img_ws, I.final_T), at<uint32_t>(img_ws, I.n_contrib),
                         at<uint32_t>(img_ws, I.tile_max), dL_dout_color, rows, flags,
                         at<uint32_t>(img_ws, I.tile_order),
@@ -311,7 +312,7 @@ int gsr_backward(const GsrParams* p, const int32_t* radii, const void* geom_ws, 
   }
   {
     StageTimer t(p, GSR_STAGE_PREPROCESS_BWD, s);
-    launch_preprocess_bwd(*p, radii, rec, rows, flags, *grads, s);
+    launch_preprocess_bwd(*p, radii, rec, at<uint32_t>(geom_ws, L.slot_base), rows, flags, *grads, s);
   }
   return check(p, s, "preprocess_bwd");
 }

@@ -21,7 +21,8 @@ struct __attribute__((aligned(64))) GeomRec {
   float x, y, cxx, cxy;          // pixel-space mean, conic xx / xy
   float cyy, opacity, r, g;      // conic yy, opacity, colour
   float b, ext_x, ext_y;         // colour, conservative half-extent of the alpha >= 1/255 ellipse
-  uint32_t offs_excl;            // first slot of this Gaussian in the unsorted instance array
+  uint32_t reserved0;            // (the per-Gaussian row slot lives in GeomLayout::slot_base: a 4-byte write into
+                                 //  these 64-byte records costs a read-modify-write of the line)
   uint32_t rect_min;             // tile rect min: x | y << 16
   uint32_t rect_wh;              // tile rect width | height << 16
   float depth;                   // view-space z
@@ -53,7 +54,7 @@ constexpr int PRE_BLOCK = 256;      // Gaussians per preprocess / duplicate bloc
 
 // ---- workspace layouts (host + device agree through these helpers) -------------------------
 struct GeomLayout {
-  size_t rec, bin, offsets, block_sums, block_offs, block_vis, block_vis_offs, total, bytes;
+  size_t rec, bin, offsets, slot_base, block_sums, block_offs, block_vis, block_vis_offs, total, bytes;
   int nblocks;
   __host__ __device__ explicit GeomLayout(int P) {
     nblocks = (P + PRE_BLOCK - 1) / PRE_BLOCK;
@@ -61,6 +62,7 @@ struct GeomLayout {
     rec = o;        o = align_up(o + sizeof(GeomRec) * (size_t)P, 256);
     bin = o;        o = align_up(o + sizeof(BinInfo) * (size_t)P, 256);
     offsets = o;    o = align_up(o + 4 * (size_t)P, 256);
+    slot_base = o;  o = align_up(o + 4 * (size_t)P, 256);   // first gradient-row slot of every Gaussian (index-major)
     block_sums = o; o = align_up(o + 4 * (size_t)(nblocks + 1), 256);
     block_offs = o; o = align_up(o + 4 * (size_t)(nblocks + 1), 256);
     block_vis = o;  o = align_up(o + 4 * (size_t)(nblocks + 1), 256);        // visible Gaussians per block

@@ -11,11 +11,12 @@ void launch_preprocess_fwd(const GsrParams& p, GeomRec* rec, BinInfo* bin, uint3
 // exclusive scans of up to two per-block arrays in one launch (block 0: a, block 1: b); total_x = grand total
 void launch_scan_block_sums(const uint32_t* sums_a, uint32_t* offs_a, uint32_t* total_a, const uint32_t* sums_b,
                             uint32_t* offs_b, uint32_t* total_b, int nb, hipStream_t s);
-void launch_preprocess_bwd(const GsrParams& p, const int32_t* radii, const GeomRec* rec, const GradRow* rows,
+void launch_preprocess_bwd(const GsrParams& p, const int32_t* radii, const GeomRec* rec, const uint32_t* slot_base,
+                           const GradRow* rows,
                            const uint8_t* row_flags, const GsrGrads& g, hipStream_t s);
 
 // binning.hip
-void launch_duplicate_with_keys(int P, int grid_x, const BinInfo* bin, const uint32_t* block_offs, GeomRec* rec,
+void launch_duplicate_with_keys(int P, int grid_x, const BinInfo* bin, const uint32_t* block_offs, uint32_t* slot_base,
                                 uint32_t* point_offsets, uint64_t* keys, uint32_t* vals, hipStream_t s);
 // returns true when the sorted result ended in (keys_b, vals_b)
 bool launch_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, uint32_t n,
@@ -27,7 +28,7 @@ inline int sort_passes(int end_bit) { return (end_bit + RADIX_BITS - 1) / RADIX_
 void launch_identify_tile_ranges(uint32_t R, const uint64_t* keys, uint2* ranges, hipStream_t s);
 void launch_build_tile_order(int tiles, const uint2* ranges, uint32_t* order, hipStream_t s);
 void launch_compact_visible(int P, const BinInfo* bin, const uint32_t* block_vis_offs, const uint32_t* block_offs,
-                            GeomRec* rec, uint32_t* dkey, uint32_t* didx, hipStream_t s);
+                            uint32_t* slot_base, uint32_t* dkey, uint32_t* didx, hipStream_t s);
 void launch_gather_tiles(uint32_t V, const uint32_t* didx, const BinInfo* bin, uint32_t* tiles_sorted, uint2* rect_sorted,
                          uint32_t* block_sums2, hipStream_t s);
 void launch_emit_instances(uint32_t V, int grid_x, const uint32_t* didx, const uint32_t* tiles_sorted,
@@ -42,6 +43,7 @@ void launch_render_fwd(int W, int H, const uint2* ranges, const uint32_t* point_
                        const uint32_t* tile_order, uint32_t* queue, hipStream_t s,
                        unsigned long long* stats = nullptr);
 void launch_render_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
+                       const uint32_t* slot_base,
                        const float* bg, const float* final_T, const uint32_t* n_contrib, const uint32_t* tile_max,
                        const float* dL_dpix, GradRow* rows, uint8_t* row_flags, const uint32_t* tile_order,
                        uint32_t* queue, hipStream_t s);

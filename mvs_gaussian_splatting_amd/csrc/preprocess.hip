@@ -248,7 +248,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
             tiles = (uint32_t)area;
             g.x = mx; g.y = my;
             g.cxx = pr.c * det_inv; g.cxy = -pr.b * det_inv; g.cyy = pr.a * det_inv;
-            g.offs_excl = 0;
+            g.reserved0 = 0;
             g.rect_min = (uint32_t)x0 | ((uint32_t)y0 << 16);
             g.rect_wh = (uint32_t)(x1 - x0) | ((uint32_t)(y1 - y0) << 16);
             g.depth = vz;
@@ -376,6 +376,7 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t* _
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(GsrParams p, const int32_t* __restrict__ radii,
                                                                    const GeomRec* __restrict__ rec,
+                                                                   const uint32_t* __restrict__ slot_base,
                                                                    const GradRow* __restrict__ rows,
                                                                    const uint8_t* __restrict__ row_flags,
                                                                    GsrGrads g) {
@@ -417,9 +418,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(GsrParams p, 
     const GeomRec r = rec[idx];
     // ---- (0) deterministic sum of this Gaussian's instance rows -------------------------
     const uint32_t n = (r.rect_wh & 0xffffu) * (r.rect_wh >> 16);
+    const uint32_t slot0 = slot_base[idx];
     float dcxx = 0.f, dcxy = 0.f, dcyy = 0.f;
     for (uint32_t k = 0; k < n; ++k) {
-      const uint32_t s = r.offs_excl + k;
+      const uint32_t s = slot0 + k;
       if (row_flags[s]) {
         const GradRow q = rows[s];
         dm2x += q.dmx; dm2y += q.dmy; dcxx += q.dcxx; dcxy += q.dcxy; dcyy += q.dcyy;
@@ -730,10 +732,10 @@ void launch_scan_block_sums(const uint32_t* sums_a, uint32_t* offs_a, uint32_t* 
   hipLaunchKernelGGL(scan_block_sums_kernel, dim3(sums_b ? 2 : 1), dim3(1024), 0, s, sums_a, offs_a, total_a, sums_b,
                      offs_b, total_b, nb);
 }
-void launch_preprocess_bwd(const GsrParams& p, const int32_t* radii, const GeomRec* rec, const GradRow* rows,
-                           const uint8_t* row_flags, const GsrGrads& g, hipStream_t s) {
+void launch_preprocess_bwd(const GsrParams& p, const int32_t* radii, const GeomRec* rec, const uint32_t* slot_base,
+                           const GradRow* rows, const uint8_t* row_flags, const GsrGrads& g, hipStream_t s) {
   const int nb = (p.P + PRE_BLOCK - 1) / PRE_BLOCK;
-  if (nb > 0) hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, p, radii, rec, rows, row_flags, g);
+  if (nb > 0) hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, p, radii, rec, slot_base, rows, row_flags, g);
 }
 
 }  // namespace gsr

@@ -294,7 +294,8 @@ __device__ inline float wave_sum4(float q0, float q1, float q2, float q3) {
 __device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, float4* sB, float* sC, int W, int H,
                                                 int grid_x, const uint2* __restrict__ ranges,
                                                 const uint32_t* __restrict__ point_list,
-                                                const GeomRec* __restrict__ rec, const float* __restrict__ bg,
+                                                const GeomRec* __restrict__ rec,
+                                                const uint32_t* __restrict__ slot_base, const float* __restrict__ bg,
                                                 const float* __restrict__ final_T,
                                                 const uint32_t* __restrict__ n_contrib,
                                                 const uint32_t* __restrict__ tile_max,
@@ -339,7 +340,8 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, floa
   // records one round ahead, walking the list back to front
   auto load_id = [&](uint32_t lo, uint32_t top) { return point_list[start + min(lo + lane, top - 1)]; };
   auto load_rec = [&](uint32_t id) {
-    load_staged<true>(rec, id, st);
+    load_staged<false>(rec, id, st);
+    st.q2.w = __uint_as_float(slot_base[id]);
     const uint2 rr = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(rec + id) + 48);
     st.rect_min = rr.x;
     st.rect_wh = rr.y;
@@ -452,6 +454,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE, 6) void render_bwd_kernel(i
                                                           const uint2* __restrict__ ranges,
                                                           const uint32_t* __restrict__ point_list,
                                                           const GeomRec* __restrict__ rec,
+                                                          const uint32_t* __restrict__ slot_base,
                                                           const float* __restrict__ bg,
                                                           const float* __restrict__ final_T,
                                                           const uint32_t* __restrict__ n_contrib,
@@ -466,7 +469,8 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE, 6) void render_bwd_kernel(i
   const int slot = blockIdx.x * WAVES_PER_BLOCK + wid;
   if (slot >= num_tiles) return;
   const int tile = __builtin_amdgcn_readfirstlane((int)tile_order[slot]);
-  render_bwd_tile(tile, sA[wid], sB[wid], sC[wid], W, H, grid_x, ranges, point_list, rec, bg, final_T, n_contrib, tile_max, dL_dpix,
+  render_bwd_tile(tile, sA[wid], sB[wid], sC[wid], W, H, grid_x, ranges, point_list, rec, slot_base, bg, final_T, n_contrib,
+                  tile_max, dL_dpix,
                   rows, row_flags);
 }
 
@@ -484,14 +488,14 @@ void launch_render_fwd(int W, int H, const uint2* ranges, const uint32_t* point_
                        point_list, rec, bg, out_color, final_T, n_contrib, tile_max, stats);
 }
 void launch_render_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
-                       const float* bg, const float* final_T, const uint32_t* n_contrib, const uint32_t* tile_max,
+                       const uint32_t* slot_base, const float* bg, const float* final_T, const uint32_t* n_contrib, const uint32_t* tile_max,
                        const float* dL_dpix, GradRow* rows, uint8_t* row_flags, const uint32_t* tile_order,
                        uint32_t* queue, hipStream_t s) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   (void)queue;
   const int nblk = (gx * gy + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
   hipLaunchKernelGGL(render_bwd_kernel, dim3(nblk), dim3(WAVES_PER_BLOCK * WAVE), 0, s, W, H, gx, gx * gy, tile_order, ranges, point_list, rec,
-                     bg, final_T, n_contrib, tile_max, dL_dpix, rows, row_flags);
+                     slot_base, bg, final_T, n_contrib, tile_max, dL_dpix, rows, row_flags);
 }
 
 }  // namespace gsr
