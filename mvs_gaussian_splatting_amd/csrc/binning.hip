@@ -222,9 +222,11 @@ __device__ inline uint32_t digit_of(KeyT k, int shift, uint32_t mask) { return (
 
 template <typename KeyT>
 __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT* __restrict__ keys, uint32_t n,
-                                                                  int shift, uint32_t mask, uint32_t nblocks,
+                                                                  const uint32_t* __restrict__ n_dev, int shift,
+                                                                  uint32_t mask, uint32_t nblocks,
                                                                   uint32_t* __restrict__ hist) {
   __shared__ uint32_t h[RADIX];
+  if (n_dev) n = *n_dev;     // element count known only on the device (grid sized for the capacity)
   const int tid = threadIdx.x;
 #pragma unroll
   for (int d = tid; d < RADIX; d += SORT_THREADS) h[d] = 0;
@@ -277,10 +279,11 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(uint32_t* __restrict
 template <typename KeyT>
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, KeyT* __restrict__ keys_out,
-    uint32_t* __restrict__ vals_out, uint32_t n, int shift, uint32_t mask, uint32_t nblocks,
-    const uint32_t* __restrict__ hist,
-    const uint32_t* __restrict__ totals) {
+    uint32_t* __restrict__ vals_out, uint32_t n, const uint32_t* __restrict__ n_dev, int shift, uint32_t mask,
+    uint32_t nblocks, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals) {
   constexpr int NW = SORT_THREADS / WAVE;
+  if (n_dev) n = *n_dev;
+  if (blockIdx.x * SORT_TILE >= n) return;   // block beyond the device-side count (uniform: no barrier crossed)
   __shared__ KeyT xbuf[SORT_TILE];            // exchange buffer: keys first, then reused for the values
   __shared__ uint32_t wave_hist[NW][RADIX];   // per-wave digit counts, then exclusive wave prefixes
   __shared__ uint32_t digit_start[RADIX];     // first local slot of every digit
@@ -488,9 +491,10 @@ void launch_duplicate_with_keys(int P, int grid_x, const BinInfo* bin, const uin
                        point_offsets, keys, vals);
 }
 
+// n = element count, or the capacity when n_dev (device-side count) is given
 template <typename KeyT>
 static bool sort_pairs_impl(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t* vals_b, uint32_t n, int end_bit,
-                            void* scratch, hipStream_t s) {
+                            void* scratch, hipStream_t s, const uint32_t* n_dev = nullptr) {
   if (n == 0 || end_bit <= 0) return false;
   const SortLayout L(n);
   uint32_t* hist = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + L.hist);
@@ -501,11 +505,11 @@ static bool sort_pairs_impl(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32
     const int shift = pass * RADIX_BITS;
     const int nbits = end_bit - shift < RADIX_BITS ? end_bit - shift : RADIX_BITS;   // ignore bits >= end_bit
     const uint32_t mask = (1u << nbits) - 1u;
-    hipLaunchKernelGGL(radix_hist_kernel<KeyT>, dim3(L.nblocks), dim3(SORT_THREADS), 0, s, kin, n, shift, mask,
+    hipLaunchKernelGGL(radix_hist_kernel<KeyT>, dim3(L.nblocks), dim3(SORT_THREADS), 0, s, kin, n, n_dev, shift, mask,
                        L.nblocks, hist);
     hipLaunchKernelGGL(radix_rowscan_kernel, dim3(RADIX), dim3(256), 0, s, hist, L.nblocks, totals);
     hipLaunchKernelGGL(radix_scatter_kernel<KeyT>, dim3(L.nblocks), dim3(SORT_THREADS), 0, s, kin, vin, kout, vout, n,
-                       shift, mask, L.nblocks, hist, totals);
+                       n_dev, shift, mask, L.nblocks, hist, totals);
     KeyT* tk = kin; kin = kout; kout = tk;
     uint32_t* tv = vin; vin = vout; vout = tv;
   }
@@ -516,8 +520,8 @@ bool launch_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uin
   return sort_pairs_impl<uint64_t>(keys_a, vals_a, keys_b, vals_b, n, end_bit, scratch, s);
 }
 bool launch_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n,
-                           int end_bit, void* scratch, hipStream_t s) {
-  return sort_pairs_impl<uint32_t>(keys_a, vals_a, keys_b, vals_b, n, end_bit, scratch, s);
+                           int end_bit, void* scratch, hipStream_t s, const uint32_t* n_dev) {
+  return sort_pairs_impl<uint32_t>(keys_a, vals_a, keys_b, vals_b, n, end_bit, scratch, s, n_dev);
 }
 
 void launch_compact_visible(int P, const BinInfo* bin, const uint32_t* block_vis_offs, const uint32_t* block_offs,

@@ -164,14 +164,39 @@ int gsr_forward_preprocess(const GsrParams* p, void* geom_ws, int32_t* radii, vo
     StageTimer t(p, GSR_STAGE_SCAN, s);
     launch_scan_block_sums(at<uint32_t>(geom_ws, L.block_sums), at<uint32_t>(geom_ws, L.block_offs), total,
                            at<uint32_t>(geom_ws, L.block_vis), at<uint32_t>(geom_ws, L.block_vis_offs), total + 1,
-                           L.nblocks, s);
+                           L.nblocks, s, p->counts_pinned);
   }
   if (int rc = check(p, s, "scan_block_sums")) return rc;
-  uint32_t host[2] = {0, 0};
-  GSR_HIP(hipMemcpyAsync(host, total, sizeof(host), hipMemcpyDeviceToHost, s));
-  GSR_HIP(hipStreamSynchronize(s));
-  *num_rendered = host[0];
-  *num_visible = host[1];
+  hipEvent_t counted = nullptr;
+  if (p->counts_pinned) {
+    GSR_HIP(hipEventCreateWithFlags(&counted, hipEventDisableTiming));
+    GSR_HIP(hipEventRecord(counted, s));
+  }
+  if (p->binning_mode == GSR_BINNING_TWO_LEVEL) {
+    // first half of the two-level binning needs no host-side count: enqueue it before the read-back so that the
+    // GPU sorts while the host round-trips (compaction + 32-bit depth sort of the visible Gaussians, device-side V)
+    StageTimer t(p, GSR_STAGE_SORT, s);
+    launch_compact_visible(p->P, at<BinInfo>(geom_ws, L.bin), at<uint32_t>(geom_ws, L.block_vis_offs),
+                           at<uint32_t>(geom_ws, L.block_offs), at<uint32_t>(geom_ws, L.slot_base),
+                           at<uint32_t>(geom_ws, L.dkey_a), at<uint32_t>(geom_ws, L.didx_a), s);
+    launch_sort_pairs_u32(at<uint32_t>(geom_ws, L.dkey_a), at<uint32_t>(geom_ws, L.didx_a),
+                          at<uint32_t>(geom_ws, L.dkey_b), at<uint32_t>(geom_ws, L.didx_b), (uint32_t)p->P, 32,
+                          at<char>(geom_ws, L.dsort), s, total + 1);
+  }
+  if (int rc = check(p, s, "depth_sort")) return rc;
+  if (counted) {
+    const hipError_t e = hipEventSynchronize(counted);     // waits for the scan kernel only
+    (void)hipEventDestroy(counted);
+    if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize(counted)");
+    *num_rendered = p->counts_pinned[0];
+    *num_visible = p->counts_pinned[1];
+  } else {
+    uint32_t host[2] = {0, 0};
+    GSR_HIP(hipMemcpyAsync(host, total, sizeof(host), hipMemcpyDeviceToHost, s));
+    GSR_HIP(hipStreamSynchronize(s));
+    *num_rendered = host[0];
+    *num_visible = host[1];
+  }
   return 0;
 }
 
@@ -219,10 +244,6 @@ int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t b
       }
       point_list = in_b ? vb : va;
     } else {
-      uint32_t* dka = at<uint32_t>(bin_ws, B.dkey_a);
-      uint32_t* dkb = at<uint32_t>(bin_ws, B.dkey_b);
-      uint32_t* dia = at<uint32_t>(bin_ws, B.didx_a);
-      uint32_t* dib = at<uint32_t>(bin_ws, B.didx_b);
       uint32_t* ita = at<uint32_t>(bin_ws, B.itile_a);
       uint32_t* itb = at<uint32_t>(bin_ws, B.itile_b);
       uint32_t* iga = at<uint32_t>(bin_ws, B.ig_a);
@@ -230,15 +251,8 @@ int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t b
       uint32_t* tiles_sorted = at<uint32_t>(bin_ws, B.tiles_sorted);
       uint32_t* bsum2 = at<uint32_t>(bin_ws, B.bsum2);
       uint32_t* boffs2 = at<uint32_t>(bin_ws, B.boffs2);
-      const uint32_t* didx_sorted;
-      {
-        StageTimer t(p, GSR_STAGE_SORT, s);     // depth sort of the visible Gaussians
-        launch_compact_visible(p->P, bin, at<uint32_t>(geom_ws, L.block_vis_offs), at<uint32_t>(geom_ws, L.block_offs),
-                               at<uint32_t>(geom_ws, L.slot_base), dka, dia, s);
-        const bool in_b = launch_sort_pairs_u32(dka, dia, dkb, dib, V, 32, at<char>(bin_ws, B.sort), s);
-        didx_sorted = in_b ? dib : dia;
-      }
-      if (int rc = check(p, s, "depth_sort")) return rc;
+      // depth-sorted Gaussian indices: produced by stage 1 (gsr_forward_preprocess) in the geometry workspace
+      const uint32_t* didx_sorted = at<uint32_t>(geom_ws, (sort_passes(32) & 1) ? L.didx_b : L.didx_a);
       {
         StageTimer t(p, GSR_STAGE_DUPLICATE, s);   // instances emitted in depth order
         uint2* rect_sorted = at<uint2>(bin_ws, B.rect_sorted);

@@ -54,7 +54,8 @@ constexpr int PRE_BLOCK = 256;      // Gaussians per preprocess / duplicate bloc
 
 // ---- workspace layouts (host + device agree through these helpers) -------------------------
 struct GeomLayout {
-  size_t rec, bin, offsets, slot_base, block_sums, block_offs, block_vis, block_vis_offs, total, bytes;
+  size_t rec, bin, offsets, slot_base, block_sums, block_offs, block_vis, block_vis_offs, total;
+  size_t dkey_a, dkey_b, didx_a, didx_b, dsort, bytes;   // depth sort of the visible Gaussians (capacity P)
   int nblocks;
   __host__ __device__ explicit GeomLayout(int P) {
     nblocks = (P + PRE_BLOCK - 1) / PRE_BLOCK;
@@ -68,6 +69,11 @@ struct GeomLayout {
     block_vis = o;  o = align_up(o + 4 * (size_t)(nblocks + 1), 256);        // visible Gaussians per block
     block_vis_offs = o; o = align_up(o + 4 * (size_t)(nblocks + 1), 256);
     total = o;      o = align_up(o + 64, 256);                               // [0] = R (instances), [1] = V (visible)
+    dkey_a = o;     o = align_up(o + 4 * (size_t)P, 256);
+    dkey_b = o;     o = align_up(o + 4 * (size_t)P, 256);
+    didx_a = o;     o = align_up(o + 4 * (size_t)P, 256);
+    didx_b = o;     o = align_up(o + 4 * (size_t)P, 256);
+    dsort = o;      o = align_up(o + 4 * (size_t)(1 << 9) * ((size_t)P / 4096 + 2) + 4096, 256);
     bytes = o;
   }
 };
@@ -117,7 +123,7 @@ struct BinLayout {
   // mode 1
   size_t keys_a, keys_b, vals_a, vals_b;
   // mode 0
-  size_t dkey_a, dkey_b, didx_a, didx_b, tiles_sorted, rect_sorted, bsum2, boffs2, itile_a, itile_b, ig_a, ig_b;
+  size_t tiles_sorted, rect_sorted, bsum2, boffs2, itile_a, itile_b, ig_a, ig_b;
   size_t sort, bytes;
   uint32_t nblocks2;
   __host__ __device__ BinLayout(uint32_t R, uint32_t V, int mode) {
@@ -125,7 +131,7 @@ struct BinLayout {
     nblocks2 = (uint32_t)((v + PRE_BLOCK - 1) / PRE_BLOCK);
     size_t o = 0;
     keys_a = keys_b = vals_a = vals_b = 0;
-    dkey_a = dkey_b = didx_a = didx_b = tiles_sorted = rect_sorted = bsum2 = boffs2 = itile_a = itile_b = ig_a = ig_b = 0;
+    tiles_sorted = rect_sorted = bsum2 = boffs2 = itile_a = itile_b = ig_a = ig_b = 0;
     if (mode == 1) {
       keys_a = o; o = align_up(o + 8 * n, 256);
       keys_b = o; o = align_up(o + 8 * n, 256);
@@ -133,10 +139,6 @@ struct BinLayout {
       vals_b = o; o = align_up(o + 4 * n, 256);
       sort = o;   o = align_up(o + SortLayout((uint32_t)n).bytes, 256);
     } else {
-      dkey_a = o; o = align_up(o + 4 * v, 256);
-      dkey_b = o; o = align_up(o + 4 * v, 256);
-      didx_a = o; o = align_up(o + 4 * v, 256);
-      didx_b = o; o = align_up(o + 4 * v, 256);
       tiles_sorted = o; o = align_up(o + 4 * v, 256);
       rect_sorted = o; o = align_up(o + 8 * v, 256);
       bsum2 = o;  o = align_up(o + 4 * (size_t)(nblocks2 + 1), 256);
@@ -145,8 +147,7 @@ struct BinLayout {
       itile_b = o; o = align_up(o + 4 * n, 256);
       ig_a = o;   o = align_up(o + 4 * n, 256);
       ig_b = o;   o = align_up(o + 4 * n, 256);
-      const size_t s1 = SortLayout((uint32_t)v).bytes, s2 = SortLayout((uint32_t)n).bytes;
-      sort = o;   o = align_up(o + (s1 > s2 ? s1 : s2), 256);
+      sort = o;   o = align_up(o + SortLayout((uint32_t)n).bytes, 256);
     }
     bytes = o;
   }

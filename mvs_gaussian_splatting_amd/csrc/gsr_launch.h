@@ -10,7 +10,8 @@ void launch_preprocess_fwd(const GsrParams& p, GeomRec* rec, BinInfo* bin, uint3
                            int32_t* radii, hipStream_t s);
 // exclusive scans of up to two per-block arrays in one launch (block 0: a, block 1: b); total_x = grand total
 void launch_scan_block_sums(const uint32_t* sums_a, uint32_t* offs_a, uint32_t* total_a, const uint32_t* sums_b,
-                            uint32_t* offs_b, uint32_t* total_b, int nb, hipStream_t s);
+                            uint32_t* offs_b, uint32_t* total_b, int nb, hipStream_t s,
+                            uint32_t* host_mirror = nullptr);
 void launch_preprocess_bwd(const GsrParams& p, const int32_t* radii, const GeomRec* rec, const uint32_t* slot_base,
                            const GradRow* rows,
                            const uint8_t* row_flags, const GsrGrads& g, hipStream_t s);
@@ -21,8 +22,9 @@ void launch_duplicate_with_keys(int P, int grid_x, const BinInfo* bin, const uin
 // returns true when the sorted result ended in (keys_b, vals_b)
 bool launch_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, uint32_t n,
                        int end_bit, void* scratch, hipStream_t s);
+// n_dev != NULL: the element count is read from device memory and n is the capacity the grid is sized for
 bool launch_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n,
-                           int end_bit, void* scratch, hipStream_t s);
+                           int end_bit, void* scratch, hipStream_t s, const uint32_t* n_dev = nullptr);
 void launch_identify_tile_ranges_u32(uint32_t R, const uint32_t* tiles, uint2* ranges, hipStream_t s);
 inline int sort_passes(int end_bit) { return (end_bit + RADIX_BITS - 1) / RADIX_BITS; }
 void launch_identify_tile_ranges(uint32_t R, const uint64_t* keys, uint2* ranges, hipStream_t s);

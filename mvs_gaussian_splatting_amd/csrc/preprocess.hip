@@ -340,7 +340,8 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t* _
                                                                 uint32_t* __restrict__ total_a,
                                                                 const uint32_t* __restrict__ sums_b,
                                                                 uint32_t* __restrict__ offs_b,
-                                                                uint32_t* __restrict__ total_b, int nb) {
+                                                                uint32_t* __restrict__ total_b, int nb,
+                                                                uint32_t* __restrict__ host_mirror) {
   __shared__ uint32_t wave_tot[1024 / WAVE];
   __shared__ uint32_t carry_s;
   const uint32_t* __restrict__ block_sums = blockIdx.x == 0 ? sums_a : sums_b;
@@ -366,6 +367,7 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t* _
   if (tid == 0) {
     block_offs[nb] = carry_s;
     *total = carry_s;
+    if (host_mirror) host_mirror[blockIdx.x] = carry_s;   // pinned host memory: visible once the kernel has completed
   }
 }
 
@@ -728,9 +730,9 @@ void launch_preprocess_fwd(const GsrParams& p, GeomRec* rec, BinInfo* bin, uint3
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, p, rec, bin, block_sums, block_vis, radii);
 }
 void launch_scan_block_sums(const uint32_t* sums_a, uint32_t* offs_a, uint32_t* total_a, const uint32_t* sums_b,
-                            uint32_t* offs_b, uint32_t* total_b, int nb, hipStream_t s) {
+                            uint32_t* offs_b, uint32_t* total_b, int nb, hipStream_t s, uint32_t* host_mirror) {
   hipLaunchKernelGGL(scan_block_sums_kernel, dim3(sums_b ? 2 : 1), dim3(1024), 0, s, sums_a, offs_a, total_a, sums_b,
-                     offs_b, total_b, nb);
+                     offs_b, total_b, nb, host_mirror);
 }
 void launch_preprocess_bwd(const GsrParams& p, const int32_t* radii, const GeomRec* rec, const uint32_t* slot_base,
                            const GradRow* rows, const uint8_t* row_flags, const GsrGrads& g, hipStream_t s) {

@@ -60,6 +60,19 @@ def _binning_mode() -> int:
     return _lib.BINNING_KEYS64 if os.environ.get("GSR_BINNING", "").lower() == "keys64" else _lib.BINNING_TWO_LEVEL
 
 
+_pinned = __import__("threading").local()
+
+
+def _counts_pinned() -> torch.Tensor:
+    """Per-thread pinned host buffer the scan kernel mirrors (num_rendered, num_visible) into: lets
+    gsr_forward_preprocess return as soon as the counts exist while the depth sort it enqueued keeps running."""
+    t = getattr(_pinned, "t", None)
+    if t is None:
+        t = torch.zeros(16, dtype=torch.int32).pin_memory()
+        _pinned.t = t
+    return t
+
+
 def _stream(dev: torch.device) -> int:
     return torch.cuda.current_stream(dev).cuda_stream
 
@@ -91,6 +104,7 @@ def _make_params(dev, settings: GaussianRasterizationSettings, means3D, sh, colo
     p.shs_rest = _ptr(sh_rest)
     p.act_flags = int(act_flags)
     p.binning_mode = _binning_mode()
+    p.counts_pinned = _counts_pinned().data_ptr()
     return p, [bg, view, proj, campos]
 
 

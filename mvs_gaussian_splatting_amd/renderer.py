@@ -36,12 +36,10 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier:
     """Render the scene; ``bg_color`` must be on the GPU.  Returns the reference's result dict
     (``gaussian_renderer/__init__.py:309-313``)."""
     xyz = pc.get_xyz
-    # non-leaf zero tensor whose .grad receives dL/d(mean2D) for the densification statistics
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # zero tensor whose .grad receives dL/d(mean2D) for the densification statistics.  The reference builds it as
+    # `zeros_like(...) + 0` + retain_grad() (gaussian_renderer/__init__.py:32-36); a leaf with requires_grad gets
+    # its .grad populated all the same and saves a 72 MB copy kernel per frame at 6 M Gaussians.
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device)
 
     raster_settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height),

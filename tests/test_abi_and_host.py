@@ -40,7 +40,7 @@ def test_struct_layouts_match_the_c_compiler():
 #include "gsr.h"
 int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %d\n", sizeof(GsrParams), sizeof(GsrGrads), offsetof(GsrParams, means3D),
-         offsetof(GsrParams, bg), offsetof(GsrParams, binning_mode), offsetof(GsrGrads, dL_dshs_rest), GSR_STAGE_COUNT);
+         offsetof(GsrParams, bg), offsetof(GsrParams, counts_pinned), offsetof(GsrGrads, dL_dshs_rest), GSR_STAGE_COUNT);
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -51,7 +51,7 @@ int main(void) {
         out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()
     vals = list(map(int, out))
     P, G = _lib.GsrParams, _lib.GsrGrads
-    assert vals == [C.sizeof(P), C.sizeof(G), P.means3D.offset, P.bg.offset, P.binning_mode.offset, G.dL_dshs_rest.offset,
+    assert vals == [C.sizeof(P), C.sizeof(G), P.means3D.offset, P.bg.offset, P.counts_pinned.offset, G.dL_dshs_rest.offset,
                     _lib.STAGE_COUNT]
 
 
@@ -63,7 +63,7 @@ def test_workspace_sizes_are_monotone_and_aligned():
     assert lib.gsr_geom_bytes(2000) > lib.gsr_geom_bytes(1000)
     assert lib.gsr_image_bytes(1920, 1080) >= 8 * 1920 * 1080
     assert lib.gsr_binning_bytes(10_000_000, 4_000_000, 1920, 1080, 1) >= 24 * 10_000_000
-    assert lib.gsr_binning_bytes(10_000_000, 4_000_000, 1920, 1080, 0) >= 16 * 10_000_000 + 28 * 4_000_000
+    assert lib.gsr_binning_bytes(10_000_000, 4_000_000, 1920, 1080, 0) >= 16 * 10_000_000 + 12 * 4_000_000
     assert lib.gsr_backward_bytes(1000, 5000) >= 49 * 5000
     assert all(lib.gsr_stage_name(i) for i in range(_lib.STAGE_COUNT))
 
