@@ -422,3 +422,76 @@ def test_mark_visible_matches_preprocess_near_plane(gpu_device):
     z = model.get_xyz @ cam.world_view_transform[:3, 2] + cam.world_view_transform[3, 2]
     robust = (z - 0.2).abs() > 1e-5
     assert torch.equal(vis[robust], (z > 0.2)[robust]) and 0 < int(vis.sum()) < 4000
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE configs 2 and 3 at their real sizes against the oracle
+# ---------------------------------------------------------------------------------------------------
+def test_config_C2_full_forward_matches_oracle(gpu_device):
+    """C2: 100 k Gaussians, SH degree 0, 800x800, forward only -- every integer exact, every robust pixel 1e-5."""
+    from gpu_util import forward_with_state, product_settings
+    from mvs_gaussian_splatting_amd.synthetic import CONFIGS, make_scene
+    torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    cfg = CONFIGS["C2"]
+    model, cam, bg, _ = make_scene(cfg)
+    col, radii, aux = _oracle_forward(model, cam, bg, cfg.sh_degree)
+    out = forward_with_state(gpu_device, product_settings(cam, bg, cfg.sh_degree, gpu_device), model.get_xyz,
+                             model.get_opacity, shs=model.get_features, scales=model.get_scaling,
+                             rotations=model.get_rotation)
+    assert torch.equal(out["radii"], radii)
+    assert np.array_equal(out["keys"], aux["keys"]) and np.array_equal(out["point_list"], aux["point_list"])
+    assert np.array_equal(out["ranges"], aux["ranges"])
+    robust = aux["margin"] > 1e-4
+    err = ((out["color"] - col).abs() / col.abs().clamp(min=1.0)).max(dim=0).values
+    assert float(err[robust].max()) <= 1e-5
+    assert int((~robust).sum()) <= 0.01 * robust.numel()
+    assert torch.equal(out["n_contrib"][robust], aux["n_contrib"][robust])
+
+
+def test_config_C3_masked_train_step_matches_fp64_oracle(gpu_device):
+    """C3: 1 M Gaussians, SH degree 3, 1920x1080, forward + backward.  The L1 loss is restricted to 40 tiles
+    spread over the image (mask), so that the float64 autograd oracle only has to composite those tiles; the HIP
+    path runs the whole frame and must produce the same pixels there and the same parameter gradients."""
+    from mvs_gaussian_splatting_amd import render
+    from mvs_gaussian_splatting_amd.synthetic import CONFIGS, make_scene, PipelineParams
+    from oracle import rasterize_ref
+    import os
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    cfg = CONFIGS["C3"]
+    model, cam, bg, target = make_scene(cfg)
+    gx, gy = (cfg.width + 15) // 16, (cfg.height + 15) // 16
+    tiles = [ty * gx + tx for ty in range(3, gy, 14) for tx in range(5, gx, 15)]
+    mask = torch.zeros(1, cfg.height, cfg.width)
+    for t in tiles:
+        ty, tx = divmod(t, gx)
+        mask[:, ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16] = 1.0
+    # ---- oracle, float64, only the masked tiles ----------------------------------------------------
+    d = torch.float64
+    leaves = {k: getattr(model, k).detach().to(d).requires_grad_(True)
+              for k in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")}
+    st = make_settings(cam, bg, cfg.sh_degree)
+    col, radii, aux = rasterize_ref(leaves["_xyz"], None, torch.sigmoid(leaves["_opacity"]), st,
+                                    shs=torch.cat((leaves["_features_dc"], leaves["_features_rest"]), dim=1),
+                                    scales=torch.exp(leaves["_scaling"]),
+                                    rotations=torch.nn.functional.normalize(leaves["_rotation"]),
+                                    tiles=tiles, want_aux=True, want_margin=True)
+    ((col - target.to(d)).abs() * mask.to(d)).sum().div(mask.sum() * 3).backward()
+    # ---- HIP path, whole frame -------------------------------------------------------------------------
+    dev = gpu_device
+    model.to(dev); cam.to(dev)
+    for p in model.parameters():
+        p.requires_grad_(True)
+    pkg = render(cam, model, PipelineParams(), bg.to(dev))
+    img = pkg["render"]
+    ((img - target.to(dev)).abs() * mask.to(dev)).sum().div(mask.sum().to(dev) * 3).backward()
+    m = mask[0].bool()
+    robust = (aux["margin"] > 1e-4) & m
+    err = (img.detach().cpu() - col.detach().float()).abs().max(dim=0).values
+    assert float(err[robust].max()) <= 1e-5
+    n_fragile = int(((aux["margin"] <= 1e-4) & m).sum())
+    tol = 1e-5 if n_fragile == 0 else 2e-3
+    for k, leaf in leaves.items():
+        got = getattr(model, k).grad.detach().cpu().to(d)
+        ref = leaf.grad
+        e = float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
+        assert e <= tol, (k, e, n_fragile)
