@@ -189,6 +189,11 @@ int gsr_l1_loss_fwd_bwd(const float* x, const float* gt, size_t n, float scale, 
 size_t gsr_l1_dssim_workspace_bytes(int32_t C, int32_t H, int32_t W);
 int gsr_l1_dssim_loss_fwd_bwd(const float* x, const float* gt, int32_t C, int32_t H, int32_t W, float lambda_dssim,
                               float* sums, float* dL_dx, void* workspace, void* stream);
+/* Replacement for `simple_knn._C.distCUDA2(points[N,3]) -> meanDist2[N]` (scene/gaussian_model.py:21,210; the
+ * submodule is absent from the reference): mean of the squared distances to the 3 nearest OTHER points, exact. */
+size_t gsr_knn3_workspace_bytes(int32_t N);
+int gsr_dist2_knn3(const float* points, int32_t N, float* mean_dist2, void* workspace, size_t workspace_bytes,
+                   void* stream);
 /* scene/gaussian_model.py:775-777 + train.py:130 fused: for radii>0:
  * xyz_gradient_accum += ||dL_dmeans2D.xy||, denom += 1, max_radii2D = max(max_radii2D, radii) */
 int gsr_densify_stats(int32_t P, const float* dL_dmeans2D /*[P,3]*/, const int32_t* radii,

@@ -72,6 +72,8 @@ SYMBOLS = {
     "gsr_l1_dssim_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "gsr_l1_dssim_loss_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gsr_knn3_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "gsr_dist2_knn3": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gsr_profile_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "gsr_profile_destroy": (C.c_int, [C.c_void_p]),
     "gsr_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),

@@ -468,6 +468,19 @@ int gsr_l1_dssim_loss_fwd_bwd(const float* x, const float* gt, int32_t C, int32_
   return check(nullptr, s, "l1_dssim");
 }
 
+size_t gsr_knn3_workspace_bytes(int32_t N) { return knn_workspace_bytes(N); }
+int gsr_dist2_knn3(const float* points, int32_t N, float* mean_dist2, void* workspace, size_t workspace_bytes,
+                   void* stream) {
+  if (N < 0) return fail(GSR_E_BADARG, "N < 0");
+  if (N == 0) return 0;
+  if (!points || !mean_dist2 || !workspace) return fail(GSR_E_BADARG, "NULL argument");
+  if (workspace_bytes < knn_workspace_bytes(N)) return fail(GSR_E_CAPACITY, "knn workspace too small");
+  if (((uintptr_t)workspace & 255u) != 0) return fail(GSR_E_ALIGN, "workspace must be 256-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  launch_knn3(points, N, mean_dist2, workspace, s);
+  return check(nullptr, s, "knn3");
+}
+
 int gsr_densify_stats(int32_t P, const float* dL_dmeans2D, const int32_t* radii, float* xyz_gradient_accum, float* denom,
                       float* max_radii2D, void* stream) {
   if (P < 0) return fail(GSR_E_BADARG, "P < 0");

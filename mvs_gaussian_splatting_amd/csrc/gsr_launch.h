@@ -54,6 +54,10 @@ void launch_render_bwd(int W, int H, const uint2* ranges, const uint32_t* point_
 void launch_l1_dssim(const float* x, const float* gt, int C, int H, int W, float lambda, float* sums, float* dL_dx,
                      float* maps, hipStream_t s);
 
+// knn.hip
+size_t knn_workspace_bytes(int N);
+void launch_knn3(const float* pts, int N, float* mean_dist2, void* ws, hipStream_t s);
+
 // aux.hip
 void launch_l1_loss(const float* x, const float* gt, size_t n, float scale, float* loss_sum, float* dL_dx,
                     hipStream_t s);

@@ -495,3 +495,21 @@ def test_config_C3_masked_train_step_matches_fp64_oracle(gpu_device):
         ref = leaf.grad
         e = float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
         assert e <= tol, (k, e, n_fragile)
+
+
+@pytest.mark.parametrize("N,kind", [(4, "uniform"), (1000, "uniform"), (200_000, "uniform"), (50_000, "clustered")])
+def test_distCUDA2_matches_kdtree(gpu_device, N, kind):
+    """exact 3-NN mean squared distance vs scipy's cKDTree (the reference's simple_knn is absent)."""
+    from scipy.spatial import cKDTree
+    from mvs_gaussian_splatting_amd.knn import distCUDA2
+    g = torch.Generator().manual_seed(N)
+    if kind == "uniform":
+        pts = torch.rand(N, 3, generator=g) * torch.tensor([4.0, 2.0, 1.0]) - 1.0
+    else:   # dense clusters plus far outliers: exercises the ring growth and the brute-force fallback
+        centres = torch.randn(20, 3, generator=g) * 5
+        pts = centres[torch.randint(0, 20, (N,), generator=g)] + 0.01 * torch.randn(N, 3, generator=g)
+        pts[:50] = torch.randn(50, 3, generator=g) * 200
+    got = distCUDA2(pts.to(gpu_device)).cpu().double().numpy()
+    d, _ = cKDTree(pts.double().numpy()).query(pts.double().numpy(), k=4)
+    ref = (d[:, 1:] ** 2).mean(axis=1)
+    assert np.max(np.abs(got - ref) / np.maximum(ref, 1e-12)) < 1e-4
