@@ -14,6 +14,13 @@ behavioural spec in ``SURVEY.md`` Appendix A and is pinned only on the sub-steps
 for which the reference ships importable Python (``utils/sh_utils.py``,
 ``utils/graphics_utils.py``, ``utils/loss_utils.py``): see
 ``tests/golden/make_golden.py`` and ``tests/test_oracle_golden.py``.
+
+Two independent restatements live here and are cross-checked against each other
+(``tests/test_oracle_selfcheck.py::test_c_oracle_agrees_with_pytorch_oracle``):
+
+* ``rasterizer_ref.py`` -- vectorised PyTorch, dtype-generic, differentiable (gradient truth in float64, and the
+  "pure-PyTorch CPU rasterizer" baseline of ``bench.py``);
+* ``c/gsr_oracle.c`` (+ ``c_oracle.py``) -- plain C, scalar per-pixel loops in upstream's order, forward only.
 """
 from .rasterizer_ref import (  # noqa: F401
     RasterSettings,

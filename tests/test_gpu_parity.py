@@ -513,3 +513,24 @@ def test_distCUDA2_matches_kdtree(gpu_device, N, kind):
     d, _ = cKDTree(pts.double().numpy()).query(pts.double().numpy(), k=4)
     ref = (d[:, 1:] ** 2).mean(axis=1)
     assert np.max(np.abs(got - ref) / np.maximum(ref, 1e-12)) < 1e-4
+
+
+def test_hip_forward_matches_plain_c_oracle_at_C2(gpu_device):
+    """Third leg of the triangle: HIP vs the scalar C restatement (per-pixel loops in upstream's order) at config C2."""
+    from gpu_util import forward_with_state, product_settings
+    from mvs_gaussian_splatting_amd.synthetic import CONFIGS, make_scene
+    from oracle.c_oracle import forward_c
+    cfg = CONFIGS["C2"]
+    model, cam, bg, _ = make_scene(cfg, view=2)
+    bg = torch.tensor([0.05, 0.1, 0.15])
+    c = forward_c(model.get_xyz, model.get_opacity, make_settings(cam, bg, 0), shs=model.get_features,
+                  scales=model.get_scaling, rotations=model.get_rotation)
+    out = forward_with_state(gpu_device, product_settings(cam, bg, 0, gpu_device), model.get_xyz, model.get_opacity,
+                             shs=model.get_features, scales=model.get_scaling, rotations=model.get_rotation)
+    assert np.array_equal(out["radii"].numpy(), c["radii"])
+    assert np.array_equal(out["keys"], c["keys"]) and np.array_equal(out["point_list"], c["point_list"])
+    assert np.array_equal(out["ranges"], c["ranges"])
+    err = np.abs(out["color"].numpy() - c["color"]).max(axis=0)
+    assert np.mean(err > 1e-5) < 1e-3          # only threshold-straddling pixels may differ (libm expf vs v_exp_f32)
+    assert err.max() <= 2.0 / 255.0
+    assert np.mean(out["n_contrib"].numpy().astype(np.uint32) != c["n_contrib"]) < 1e-3
