@@ -280,7 +280,7 @@ int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t b
     StageTimer t(p, GSR_STAGE_RENDER_FWD, s);
     launch_render_fwd(p->width, p->height, ranges, point_list, rec, p->bg, out_color, at<float>(img_ws, I.final_T),
                       at<uint32_t>(img_ws, I.n_contrib), at<uint32_t>(img_ws, I.tile_max),
-                      at<uint32_t>(img_ws, I.tile_order), at<uint32_t>(img_ws, I.queues), s);
+                      at<uint32_t>(img_ws, I.tile_order), s);
   }
   return check(p, s, "render_fwd");
 }
@@ -319,8 +319,7 @@ int gsr_backward(const GsrParams* p, const int32_t* radii, const void* geom_ws, 
                         at<uint32_t>(geom_ws, L.slot_base), p->bg,
                         at<float>(img_ws, I.final_T), at<uint32_t>(img_ws, I.n_contrib),
                         at<uint32_t>(img_ws, I.tile_max), dL_dout_color, rows, flags,
-                        at<uint32_t>(img_ws, I.tile_order),
-                        const_cast<uint32_t*>(at<uint32_t>(img_ws, I.queues)) + 1, s);
+                        at<uint32_t>(img_ws, I.tile_order), s);
     }
     if (int rc = check(p, s, "render_bwd")) return rc;
   }
@@ -381,7 +380,7 @@ int gsr_debug_render_stats(const GsrParams* p, const void* geom_ws, const void* 
                     sorted_views(bin_ws, R, V, p->width, p->height, p->binning_mode).point_list,
                     at<GeomRec>(geom_ws, L.rec), p->bg, out_color, at<float>(img_ws, I.final_T),
                     at<uint32_t>(img_ws, I.n_contrib), at<uint32_t>(img_ws, I.tile_max),
-                    at<uint32_t>(img_ws, I.tile_order), at<uint32_t>(img_ws, I.queues), s, stats);
+                    at<uint32_t>(img_ws, I.tile_order), s, stats);
   return check(p, s, "render_stats");
 }
 

@@ -79,7 +79,7 @@ struct GeomLayout {
 };
 
 struct ImageLayout {
-  size_t final_T, n_contrib, ranges, tile_max, tile_order, queues, bytes;
+  size_t final_T, n_contrib, ranges, tile_max, tile_order, bytes;
   int grid_x, grid_y, tiles;
   __host__ __device__ ImageLayout(int W, int H) {
     grid_x = (W + TILE - 1) / TILE;
@@ -92,7 +92,6 @@ struct ImageLayout {
     ranges = o;    o = align_up(o + 8 * (size_t)tiles, 256);
     tile_max = o;  o = align_up(o + 4 * (size_t)tiles, 256);
     tile_order = o; o = align_up(o + 4 * (size_t)tiles, 256);   // tiles, longest list first
-    queues = o;    o = align_up(o + 64, 256);                    // work-queue heads: [0] forward, [1] backward
     bytes = o;
   }
 };

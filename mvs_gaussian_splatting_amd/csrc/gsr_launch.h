@@ -42,13 +42,12 @@ void launch_reconstruct_keys(uint32_t R, const uint32_t* tile_sorted, const uint
 // render.hip
 void launch_render_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
                        const float* bg, float* out_color, float* final_T, uint32_t* n_contrib, uint32_t* tile_max,
-                       const uint32_t* tile_order, uint32_t* queue, hipStream_t s,
-                       unsigned long long* stats = nullptr);
+                       const uint32_t* tile_order, hipStream_t s, unsigned long long* stats = nullptr);
 void launch_render_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
                        const uint32_t* slot_base,
                        const float* bg, const float* final_T, const uint32_t* n_contrib, const uint32_t* tile_max,
                        const float* dL_dpix, GradRow* rows, uint8_t* row_flags, const uint32_t* tile_order,
-                       uint32_t* queue, hipStream_t s);
+                       hipStream_t s);
 
 // loss.hip
 void launch_l1_dssim(const float* x, const float* gt, int C, int H, int W, float lambda, float* sums, float* dL_dx,
