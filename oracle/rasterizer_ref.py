@@ -381,6 +381,9 @@ def _alpha_st(o, G, upstream_grad: bool):
     return torch.clamp_max(raw, ALPHA_MAX)
 
 
+COND_EPS = 2.5e-7   # ~4 ulp(float32): rounding of the three products, their sums and the pre-scaled coefficients
+
+
 def render_tiles_ref(pre: Dict[str, torch.Tensor], point_list: np.ndarray, ranges: np.ndarray,
                      settings: RasterSettings, *, tiles: Optional[Sequence[int]] = None,
                      chunk: int = 256, upstream_grad: bool = True, want_margin: bool = False):
@@ -390,7 +393,12 @@ def render_tiles_ref(pre: Dict[str, torch.Tensor], point_list: np.ndarray, range
     Returns (color[3,H,W], final_T[H,W], n_contrib[H,W] int32[, margin[H,W]]).  ``margin`` is
     the smallest relative distance of any evaluated decision of that pixel to its threshold
     (alpha vs 1/255, T vs 1e-4): pixels with a tiny margin may legitimately flip between
-    float implementations and are excluded from tight comparisons by the tests.
+    float implementations and are excluded from tight comparisons by the tests.  A pixel whose
+    float32 evaluation is ill-conditioned is flagged the same way (margin 0): for strongly
+    correlated ("needle") Gaussians the three terms of ``power`` cancel, so two float32 evaluation
+    orders (fma contraction, pre-scaled coefficients) differ by ~1e-7 x (sum of |terms|) in
+    ``power`` and by as much, relatively, in alpha; the pixel is robust only while the blended
+    bound sum_i w_i * COND_EPS * (|terms|_i) stays below 3e-6 (COND_EPS = 4 float32 ulps).
     """
     dt = pre["v_xy"].dtype
     H, W = int(settings.image_height), int(settings.image_width)
@@ -427,6 +435,7 @@ def render_tiles_ref(pre: Dict[str, torch.Tensor], point_list: np.ndarray, range
         done = ~inside
         last = torch.zeros(TILE * TILE, dtype=torch.int64)
         mg = torch.full((TILE * TILE,), float("inf"), dtype=dt) if want_margin else None
+        cond = torch.zeros(TILE * TILE, dtype=dt) if want_margin else None
         pos = s
         while pos < e and not bool(done.all()):
             n = min(chunk, e - pos)
@@ -460,6 +469,9 @@ def render_tiles_ref(pre: Dict[str, torch.Tensor], point_list: np.ndarray, range
                     m_t = torch.where(considered & valid, (cp - t_stop).abs() / t_stop,
                                       torch.full_like(alpha, float("inf")))
                     mg = torch.minimum(mg, torch.minimum(m_a, m_t).min(dim=0).values)
+                    terms = (0.5 * (g_con[:, 0:1] * dx * dx).abs() + 0.5 * (g_con[:, 2:3] * dy * dy).abs()
+                             + (g_con[:, 1:2] * dx * dy).abs())
+                    cond = cond + (w.detach() * terms * COND_EPS).sum(dim=0)
             done = done | (n_live < n)
             pos += n
         out = C + T[None, :] * bg[:, None]
@@ -468,6 +480,7 @@ def render_tiles_ref(pre: Dict[str, torch.Tensor], point_list: np.ndarray, range
         final_T[ys:ys + TILE, xs:xs + TILE] = T.detach().reshape(TILE, TILE)
         n_contrib[ys:ys + TILE, xs:xs + TILE] = last.to(torch.int32).reshape(TILE, TILE)
         if want_margin:
+            mg = torch.where(cond > 3e-6, torch.zeros_like(mg), mg)
             margin[ys:ys + TILE, xs:xs + TILE] = mg.reshape(TILE, TILE)
 
     # assemble the padded image functionally (keeps autograd)
