@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 4
+#define GSR_ABI_VERSION 5
 
 enum {
   GSR_OK = 0,
@@ -184,11 +184,34 @@ int gsr_l1_loss_fwd_bwd(const float* x, const float* gt, size_t n, float scale, 
                         float* dL_dx, void* stream);
 /* The reference's training loss (train.py:99-101) in two kernels: (1-lambda)*L1 + lambda*(1 - SSIM) with SSIM as
  * utils/loss_utils.py:23-63 (11x11 Gaussian window, sigma 1.5, zero padding, mean over C*H*W).
- * sums[0] += sum|x-gt|, sums[1] += sum SSIM (caller zero-fills; loss = (1-lambda)*sums[0]/n + lambda*(1 - sums[1]/n));
+ * dssim_mode GSR_DSSIM_ONE_MINUS_MEAN: sums[0] += sum|x-gt|, sums[1] += sum SSIM
+ *   (caller zero-fills; loss = (1-lambda)*sums[0]/n + lambda*(1 - sums[1]/n));
+ * dssim_mode GSR_DSSIM_CLAMPED_HALF (the 2D script's combined_loss, 2d_gaussian_splatting.py:196-202):
+ *   sums[1] += sum clamp((1-SSIM)/2, 0, 1); loss = (1-lambda)*sums[0]/n + lambda*sums[1]/n.
  * dL_dx receives the full gradient of that loss; workspace = 3*C*H*W floats (gsr_l1_dssim_workspace_bytes). */
+#define GSR_DSSIM_ONE_MINUS_MEAN 0
+#define GSR_DSSIM_CLAMPED_HALF 1
 size_t gsr_l1_dssim_workspace_bytes(int32_t C, int32_t H, int32_t W);
 int gsr_l1_dssim_loss_fwd_bwd(const float* x, const float* gt, int32_t C, int32_t H, int32_t W, float lambda_dssim,
-                              float* sums, float* dL_dx, void* workspace, void* stream);
+                              int32_t dssim_mode, float* sums, float* dL_dx, void* workspace, void* stream);
+
+/* BASELINE config 1: `generate_2D_gaussian_splatting(kernel_size, sigma_x, sigma_y, rho, coords, colours, image_size)`
+ * (2D-Gaussian-Splatting-main/2d_gaussian_splatting.py:44-123) without the N x 3 x H x W intermediate.
+ *   sigma_x, sigma_y, rho [N]; coords [N,2] (normalised translation, x then y); colours [N,3];
+ *   ax [K]: the kernel-grid abscissae `-5 + 10 * linspace(0, 1, K)` as the host framework evaluates them (:66-71);
+ *   out [3,H,W] channel-major (the reference returns `.permute(1, 2, 0)` of exactly that buffer, :120-121).
+ * The workspace (gsr_splat2d_workspace_bytes, 256-byte aligned) carries the forward state to gsr_splat2d_backward.
+ * not_pd_host, when non-NULL, makes the call synchronise the stream and receive 1 if any covariance has det <= 0
+ * (the reference raises ValueError there, :59-61).  Returns GSR_E_BADARG if K > min(H, W) (:93-94) or K > 2048. */
+size_t gsr_splat2d_workspace_bytes(int32_t N, int32_t H, int32_t W);
+int gsr_splat2d_forward(int32_t N, int32_t K, int32_t H, int32_t W, const float* sigma_x, const float* sigma_y,
+                        const float* rho, const float* coords, const float* colours, const float* ax, void* workspace,
+                        size_t workspace_bytes, float* out, int32_t* not_pd_host, void* stream);
+/* dL_dout [3,H,W] -> gradients of all five inputs (overwritten, not accumulated; deterministic). */
+int gsr_splat2d_backward(int32_t N, int32_t K, int32_t H, int32_t W, const float* sigma_x, const float* sigma_y,
+                         const float* rho, const float* ax, void* workspace, size_t workspace_bytes,
+                         const float* dL_dout, float* dL_dsigma_x, float* dL_dsigma_y, float* dL_drho,
+                         float* dL_dcoords, float* dL_dcolours, void* stream);
 /* Replacement for `simple_knn._C.distCUDA2(points[N,3]) -> meanDist2[N]` (scene/gaussian_model.py:21,210; the
  * submodule is absent from the reference): mean of the squared distances to the 3 nearest OTHER points, exact. */
 size_t gsr_knn3_workspace_bytes(int32_t N);

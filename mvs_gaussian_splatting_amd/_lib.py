@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class GsrParams(C.Structure):
@@ -39,6 +39,7 @@ class GsrGrads(C.Structure):
 
 ACT_SCALE_EXP, ACT_ROT_NORMALIZE, ACT_OPACITY_SIGMOID = 1, 2, 4
 BINNING_TWO_LEVEL, BINNING_KEYS64 = 0, 1
+DSSIM_ONE_MINUS_MEAN, DSSIM_CLAMPED_HALF = 0, 1
 
 
 # name -> (restype, argtypes); every symbol include/gsr.h declares
@@ -71,7 +72,11 @@ SYMBOLS = {
                                          C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsr_l1_dssim_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "gsr_l1_dssim_loss_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float,
-                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                            C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gsr_splat2d_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "gsr_splat2d_forward": (C.c_int, [C.c_int32] * 4 + [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p,
+                                      C.POINTER(C.c_int32), C.c_void_p]),
+    "gsr_splat2d_backward": (C.c_int, [C.c_int32] * 4 + [C.c_void_p] * 5 + [C.c_size_t] + [C.c_void_p] * 7),
     "gsr_knn3_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "gsr_dist2_knn3": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gsr_profile_create": (C.c_int, [C.POINTER(C.c_void_p)]),

@@ -459,12 +459,57 @@ size_t gsr_l1_dssim_workspace_bytes(int32_t C, int32_t H, int32_t W) {
   return (C <= 0 || H <= 0 || W <= 0) ? 0 : 3 * sizeof(float) * (size_t)C * (size_t)H * (size_t)W;
 }
 int gsr_l1_dssim_loss_fwd_bwd(const float* x, const float* gt, int32_t C, int32_t H, int32_t W, float lambda_dssim,
-                              float* sums, float* dL_dx, void* workspace, void* stream) {
+                              int32_t dssim_mode, float* sums, float* dL_dx, void* workspace, void* stream) {
   if (!x || !gt || !sums || !dL_dx || !workspace) return fail(GSR_E_BADARG, "NULL argument");
   if (C <= 0 || H <= 0 || W <= 0 || C > 65535) return fail(GSR_E_BADARG, "bad image shape");
+  if (dssim_mode != GSR_DSSIM_ONE_MINUS_MEAN && dssim_mode != GSR_DSSIM_CLAMPED_HALF)
+    return fail(GSR_E_BADARG, "unknown dssim_mode");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  launch_l1_dssim(x, gt, C, H, W, lambda_dssim, sums, dL_dx, static_cast<float*>(workspace), s);
+  launch_l1_dssim(x, gt, C, H, W, lambda_dssim, dssim_mode, sums, dL_dx, static_cast<float*>(workspace), s);
   return check(nullptr, s, "l1_dssim");
+}
+
+size_t gsr_splat2d_workspace_bytes(int32_t N, int32_t H, int32_t W) {
+  return (N < 0 || H <= 0 || W <= 0) ? 0 : Splat2dLayout(N, H, W).bytes;
+}
+static int splat2d_validate(int32_t N, int32_t K, int32_t H, int32_t W, const void* ws, size_t ws_bytes) {
+  if (N < 0 || H <= 0 || W <= 0 || K <= 0) return fail(GSR_E_BADARG, "bad N / K / image size");
+  if (K > H || K > W) return fail(GSR_E_BADARG, "Kernel size should be smaller or equal to the image size.");
+  if (K > splat2d_max_kernel_size()) return fail(GSR_E_BADARG, "kernel size above 2048");
+  if (!ws) return fail(GSR_E_BADARG, "NULL workspace");
+  if (((uintptr_t)ws & 255u) != 0) return fail(GSR_E_ALIGN, "workspace must be 256-byte aligned");
+  if (ws_bytes < Splat2dLayout(N, H, W).bytes) return fail(GSR_E_CAPACITY, "splat2d workspace too small");
+  return 0;
+}
+int gsr_splat2d_forward(int32_t N, int32_t K, int32_t H, int32_t W, const float* sigma_x, const float* sigma_y,
+                        const float* rho, const float* coords, const float* colours, const float* ax, void* workspace,
+                        size_t workspace_bytes, float* out, int32_t* not_pd_host, void* stream) {
+  if (int rc = splat2d_validate(N, K, H, W, workspace, workspace_bytes)) return rc;
+  if (!out || !ax) return fail(GSR_E_BADARG, "NULL argument");
+  if (N > 0 && (!sigma_x || !sigma_y || !rho || !coords || !colours)) return fail(GSR_E_BADARG, "NULL input");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  launch_splat2d_fwd(N, K, H, W, sigma_x, sigma_y, rho, coords, colours, ax, workspace, out, s);
+  if (int rc = check(nullptr, s, "splat2d_forward")) return rc;
+  if (not_pd_host) {
+    int flag = 0;
+    GSR_HIP(hipMemcpyAsync(&flag, static_cast<char*>(workspace) + Splat2dLayout(N, H, W).flag, 4, hipMemcpyDeviceToHost, s));
+    GSR_HIP(hipStreamSynchronize(s));
+    *not_pd_host = flag;
+  }
+  return 0;
+}
+int gsr_splat2d_backward(int32_t N, int32_t K, int32_t H, int32_t W, const float* sigma_x, const float* sigma_y,
+                         const float* rho, const float* ax, void* workspace, size_t workspace_bytes,
+                         const float* dL_dout, float* dL_dsigma_x, float* dL_dsigma_y, float* dL_drho,
+                         float* dL_dcoords, float* dL_dcolours, void* stream) {
+  if (int rc = splat2d_validate(N, K, H, W, workspace, workspace_bytes)) return rc;
+  if (!dL_dout || !ax) return fail(GSR_E_BADARG, "NULL argument");
+  if (N > 0 && (!sigma_x || !sigma_y || !rho || !dL_dsigma_x || !dL_dsigma_y || !dL_drho || !dL_dcoords || !dL_dcolours))
+    return fail(GSR_E_BADARG, "NULL input / gradient");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  launch_splat2d_bwd(N, K, H, W, sigma_x, sigma_y, rho, ax, workspace, dL_dout, dL_dsigma_x, dL_dsigma_y, dL_drho,
+                     dL_dcoords, dL_dcolours, s);
+  return check(nullptr, s, "splat2d_backward");
 }
 
 size_t gsr_knn3_workspace_bytes(int32_t N) { return knn_workspace_bytes(N); }

@@ -50,8 +50,22 @@ void launch_render_bwd(int W, int H, const uint2* ranges, const uint32_t* point_
                        hipStream_t s);
 
 // loss.hip
-void launch_l1_dssim(const float* x, const float* gt, int C, int H, int W, float lambda, float* sums, float* dL_dx,
-                     float* maps, hipStream_t s);
+void launch_l1_dssim(const float* x, const float* gt, int C, int H, int W, float lambda, int dssim_mode, float* sums,
+                     float* dL_dx, float* maps, hipStream_t s);
+
+// splat2d.hip (BASELINE config 1)
+struct Splat2dLayout {
+  size_t rec, flag, pre, gmask, partial, bytes;
+  int chunks, per_chunk;
+  Splat2dLayout(int N, int H, int W);
+};
+int splat2d_max_kernel_size();
+void launch_splat2d_fwd(int N, int K, int H, int W, const float* sx, const float* sy, const float* rho,
+                        const float* coords, const float* colours, const float* ax, void* ws, float* out,
+                        hipStream_t s);
+void launch_splat2d_bwd(int N, int K, int H, int W, const float* sx, const float* sy, const float* rho, const float* ax,
+                        void* ws, const float* dL_dout, float* d_sx, float* d_sy, float* d_rho, float* d_coords,
+                        float* d_colours, hipStream_t s);
 
 // knn.hip
 size_t knn_workspace_bytes(int N);

@@ -1,5 +1,6 @@
 // Fused training loss of the reference's step (train.py:99-101): (1-lambda) * L1 + lambda * (1 - SSIM), forward and
-// gradient.  SSIM as utils/loss_utils.py:23-63: 11x11 Gaussian window (sigma 1.5), depthwise,
+// gradient.  dssim_mode 1 is the 2D script's variant (2d_gaussian_splatting.py:196-202):
+// (1-lambda) * L1 + lambda * mean(clamp((1 - SSIM)/2, 0, 1)).  SSIM as utils/loss_utils.py:23-63: 11x11 Gaussian window (sigma 1.5), depthwise,
 // zero padding, C1 = 0.01^2, C2 = 0.03^2, mean over all pixels and channels.  The window is separable
 // (create_window builds it as an outer product), so every 16x16 output tile stages a 26x26 halo in LDS and
 // runs a horizontal then a vertical 11-tap pass.
@@ -23,7 +24,8 @@ __device__ inline float halo_load(const float* __restrict__ img, int W, int H, i
 
 __global__ __launch_bounds__(SS_T * SS_T) void ssim_fwd_kernel(const float* __restrict__ X, const float* __restrict__ Y,
                                                                 int W, int H, Win11 win, float lambda, float inv_n,
-                                                                float* __restrict__ sums, float* __restrict__ maps) {
+                                                                int dssim_mode, float* __restrict__ sums,
+                                                                float* __restrict__ maps) {
   __shared__ float sx[SS_H][SS_H + 1];
   __shared__ float sy[SS_H][SS_H + 1];
   __shared__ float hz[5][SS_H][SS_T + 1];   // horizontally filtered x, y, xx, yy, xy
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(SS_T * SS_T) void ssim_fwd_kernel(const float* __re
   }
   const int px = x0 + tx, py = y0 + ty;
   const bool in = px < W && py < H;
-  float s = 0.f, l1 = 0.f;
+  float s = 0.f, s_acc = 0.f, l1 = 0.f;
   if (in) {
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     const float mu1_sq = m1 * m1, mu2_sq = m2 * m2, mu12 = m1 * m2;
@@ -67,7 +69,14 @@ __global__ __launch_bounds__(SS_T * SS_T) void ssim_fwd_kernel(const float* __re
     const float N1 = 2.0f * mu12 + C1, N2 = 2.0f * s12 + C2, D1 = mu1_sq + mu2_sq + C1, D2 = s1 + s2 + C2;
     const float inv = 1.0f / (D1 * D2);
     s = N1 * N2 * inv;
-    const float dLds = -lambda * inv_n;                               // d/ds of lambda * (1 - mean s)
+    float dLds = -lambda * inv_n;                                     // d/ds of lambda * (1 - mean s)
+    if (dssim_mode == GSR_DSSIM_CLAMPED_HALF) {                       // lambda * mean(clamp((1 - s)/2, 0, 1))
+      const float d = (1.0f - s) * 0.5f;
+      dLds = (d >= 0.0f && d <= 1.0f) ? 0.5f * dLds : 0.0f;
+      s_acc = fminf(fmaxf(d, 0.0f), 1.0f);
+    } else {
+      s_acc = s;
+    }
     const float ds_dm1 = 2.0f * m2 * (N2 - N1) * inv - s * 2.0f * m1 * (D2 - D1) * inv;
     const size_t o = plane * blockIdx.z + (size_t)py * W + px;
     const size_t total = plane * gridDim.z;
@@ -76,7 +85,7 @@ __global__ __launch_bounds__(SS_T * SS_T) void ssim_fwd_kernel(const float* __re
     maps[2 * total + o] = dLds * (2.0f * N1 * inv);
     l1 = fabsf(sx[ty + SS_R][tx + SS_R] - sy[ty + SS_R][tx + SS_R]);
   }
-  s = wave_reduce_add_f32(s);
+  s = wave_reduce_add_f32(s_acc);
   l1 = wave_reduce_add_f32(l1);
   const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
   if (lane == 0) { red[0][wid] = l1; red[1][wid] = s; }
@@ -132,8 +141,8 @@ __global__ __launch_bounds__(SS_T * SS_T) void ssim_bwd_kernel(const float* __re
   }
 }
 
-void launch_l1_dssim(const float* x, const float* gt, int C, int H, int W, float lambda, float* sums, float* dL_dx,
-                     float* maps, hipStream_t s) {
+void launch_l1_dssim(const float* x, const float* gt, int C, int H, int W, float lambda, int dssim_mode, float* sums,
+                     float* dL_dx, float* maps, hipStream_t s) {
   Win11 win;
   double g[11], tot = 0.0;
   for (int i = 0; i < 11; ++i) { g[i] = exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); tot += g[i]; }
@@ -144,7 +153,8 @@ void launch_l1_dssim(const float* x, const float* gt, int C, int H, int W, float
   (void)tot;
   const dim3 grid((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, C);
   const float inv_n = 1.0f / ((float)C * (float)H * (float)W);
-  hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(SS_T * SS_T), 0, s, x, gt, W, H, win, lambda, inv_n, sums, maps);
+  hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(SS_T * SS_T), 0, s, x, gt, W, H, win, lambda, inv_n, dssim_mode, sums,
+                     maps);
   hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(SS_T * SS_T), 0, s, x, gt, W, H, win, (1.0f - lambda) * inv_n, maps, dL_dx);
 }
 

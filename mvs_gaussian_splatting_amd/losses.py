@@ -55,7 +55,7 @@ class _L1DssimLoss(torch.autograd.Function):
         with torch.cuda.device(x.device):
             stream = torch.cuda.current_stream(x.device).cuda_stream
             _lib.check(lib.gsr_l1_dssim_loss_fwd_bwd(xc.data_ptr(), gc.data_ptr(), Cn, H, W, float(lambda_dssim),
-                                                     sums.data_ptr(), grad.data_ptr(), ws.data_ptr(), stream),
+                                                     _lib.DSSIM_ONE_MINUS_MEAN, sums.data_ptr(), grad.data_ptr(), ws.data_ptr(), stream),
                        "gsr_l1_dssim_loss_fwd_bwd")
         ctx.save_for_backward(grad)
         return ((1.0 - lambda_dssim) * sums[0] / n + lambda_dssim * (1.0 - sums[1] / n)).reshape(())

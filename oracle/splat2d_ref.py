@@ -18,9 +18,11 @@ import torch
 import torch.nn.functional as F
 
 
-def splat2d_ref(kernel_size: int, sigma_x, sigma_y, rho, coords, colours, image_size=(256, 256, 3)):
+def splat2d_ref(kernel_size: int, sigma_x, sigma_y, rho, coords, colours, image_size=(256, 256, 3), ax=None):
     """-> image ``[H, W, 3]`` in [0, 1].  ``coords`` are the normalised translations of the reference
-    (``give_required_data``, :242-254)."""
+    (``give_required_data``, :242-254).  ``ax`` overrides the kernel-grid abscissae (default: ``-5 + 10 *
+    linspace(0, 1, K)`` in the working dtype, :66-71) -- the float64 truth of a float32 run uses the float32 table,
+    which is an *input* of the C ABI (``gsr_splat2d_forward``)."""
     B = colours.shape[0]
     K = kernel_size
     H, W = int(image_size[0]), int(image_size[1])
@@ -31,7 +33,9 @@ def splat2d_ref(kernel_size: int, sigma_x, sigma_y, rho, coords, colours, image_
     if (det <= 0).any():
         raise ValueError("Covariance matrix must be positive semi-definite")
     i00, i01, i11 = c11 / det, -c01 / det, c00 / det
-    ax = -5.0 + 10.0 * torch.linspace(0, 1, steps=K, dtype=dt)
+    if ax is None:
+        ax = -5.0 + 10.0 * torch.linspace(0, 1, steps=K, dtype=dt)
+    ax = ax.to(dt)
     xx = ax.view(1, K, 1)          # first coordinate runs along kernel rows (reference meshgrid, :72-76)
     yy = ax.view(1, 1, K)
     z = -0.5 * (i00 * xx * xx + 2.0 * i01 * xx * yy + i11 * yy * yy)

@@ -43,6 +43,31 @@ def main():
                         g_coords=grads[3].numpy(), g_colours=grads[4].numpy())
     print("wrote", OUT, "loss", loss.item())
 
+    # BASELINE config 1 at its full size: N = 1000 Gaussians, K = 101 (config.yml:1), 128 x 128, the script's own
+    # parameterisation (sigmoid / tanh of W's columns, :321-330) and lambda = 0.2 (:334)
+    g = torch.Generator().manual_seed(12)
+    N, K, size = 1000, 101, (128, 128, 3)
+    Wp = torch.cat([torch.rand(N, 2, generator=g), 2 * torch.rand(N, 1, generator=g) - 1,
+                    torch.logit(0.01 + 0.09 * torch.rand(N, 1, generator=g)),   # alpha: mostly unsaturated sum
+                    torch.logit(torch.rand(N, 3, generator=g).clamp(0.02, 0.98)),
+                    torch.atanh((torch.rand(N, 2, generator=g) * 2 - 1) * 0.98)], dim=1)
+    sx = torch.sigmoid(Wp[:, 0]).requires_grad_(True)
+    sy = torch.sigmoid(Wp[:, 1]).requires_grad_(True)
+    rho = torch.tanh(Wp[:, 2]).requires_grad_(True)
+    colours = (torch.sigmoid(Wp[:, 4:7]) * torch.sigmoid(Wp[:, 3]).view(N, 1)).requires_grad_(True)
+    coords = torch.tanh(Wp[:, 7:9]).requires_grad_(True)
+    target = torch.rand(*size, generator=g).half().float()      # exactly representable in the float16 fixture
+    img = ns["generate_2D_gaussian_splatting"](K, sx, sy, rho, coords, colours, size, "cpu")
+    loss = ns["combined_loss"](img, target, lambda_param=0.2)
+    grads = torch.autograd.grad(loss, [sx, sy, rho, coords, colours])
+    out = OUT.replace("splat2d.npz", "splat2d_c1.npz")
+    np.savez_compressed(out, K=K, size=np.array(size), sx=sx.detach().numpy(), sy=sy.detach().numpy(),
+                        rho=rho.detach().numpy(), coords=coords.detach().numpy(), colours=colours.detach().numpy(),
+                        target=target.numpy().astype(np.float16), image=img.detach().numpy(), loss=loss.item(),
+                        g_sx=grads[0].numpy(), g_sy=grads[1].numpy(), g_rho=grads[2].numpy(),
+                        g_coords=grads[3].numpy(), g_colours=grads[4].numpy())
+    print("wrote", out, "loss", loss.item(), "clamped px", int((img >= 1).sum()))
+
 
 if __name__ == "__main__":
     main()

@@ -79,3 +79,20 @@ def test_splat2d_matches_reference_functions():
     for got, k in zip(grads, ["g_sx", "g_sy", "g_rho", "g_coords", "g_colours"]):
         ref = torch.tensor(g[k])
         assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-9, k
+
+
+def test_splat2d_full_config1_matches_reference_functions():
+    """BASELINE config 1 at its real size (N = 1000, K = 101, 128 x 128, lambda 0.2): oracle vs the reference's own
+    function bodies (tests/golden/make_golden_splat2d.py)."""
+    from oracle.splat2d_ref import splat2d_ref, combined_loss_ref
+    g = np.load(os.path.join(GOLD, "splat2d_c1.npz"))
+    t = lambda k: torch.tensor(g[k]).requires_grad_(True)  # noqa: E731
+    sx, sy, rho, coords, col = t("sx"), t("sy"), t("rho"), t("coords"), t("colours")
+    img = splat2d_ref(int(g["K"]), sx, sy, rho, coords, col, tuple(int(v) for v in g["size"]))
+    assert float((img.detach() - torch.tensor(g["image"])).abs().max()) < 2e-5
+    loss = combined_loss_ref(img, torch.tensor(g["target"].astype(np.float32)), 0.2)
+    assert math.isclose(loss.item(), float(g["loss"]), rel_tol=1e-5)
+    grads = torch.autograd.grad(loss, [sx, sy, rho, coords, col])
+    for got, k in zip(grads, ["g_sx", "g_sy", "g_rho", "g_coords", "g_colours"]):
+        ref = torch.tensor(g[k])
+        assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-9, k
