@@ -178,24 +178,49 @@ def main():
     visible = int((radii > 0).sum())
 
     def timed(fn, k):
+        """-> (wall seconds of the K steps, MAX over ranks; per-step device ms of this rank from events recorded on
+        the stream the kernels run on -- the operator launches on torch's current stream)."""
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(k + 1)]
         barrier()
         t0 = time.perf_counter()
-        for _ in range(k):
+        evs[0].record()
+        for i in range(k):
             fn()
+            evs[i + 1].record()
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        return dt
+        per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(k))
+        return dt, per_step
+
+    def pct(v, q):
+        return round(v[min(len(v) - 1, int(q * len(v)))], 4)
+
+    def copy_ceiling():
+        """Measured device-to-device copy rate (bytes read + bytes written per second): the practical HBM ceiling
+        the streaming stages are judged against, next to the 8 TB/s vendor peak."""
+        n = 1 << 28                                             # 1 GiB of float32
+        a = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+        b = torch.empty_like(a)
+        for _ in range(3):
+            b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return 10 * 2 * 4 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
     K = args.steps
     prof = _lib.StageProfile()
     with prof:
-        t_fwd = timed(fwd_step, K)
+        t_fwd, fwd_steps = timed(fwd_step, K)
         stages_fwd = prof.collect()
-        t_train = timed(train_step, K)
+        t_train, train_steps = timed(train_step, K)
         stages_train = prof.collect()
     prof.close()
 
@@ -248,6 +273,9 @@ def main():
             "ms_per_step": round(train_ms, 3), "fwd_ms_per_step": round(fwd_ms, 3),
             "train_mpixels_per_s": round(world * W * H / (t_train / K) / 1e6, 2),
             "fwd_fps": round(1e3 / fwd_ms, 2),
+            "fwd_step_ms_p10_p50_p90": [pct(fwd_steps, 0.1), pct(fwd_steps, 0.5), pct(fwd_steps, 0.9)],
+            "train_step_ms_p10_p50_p90": [pct(train_steps, 0.1), pct(train_steps, 0.5), pct(train_steps, 0.9)],
+            "hbm_copy_measured_GBs": round(copy_ceiling(), 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {P} Gaussians, SH degree {cfg.sh_degree}, {W}x{H}, one view per GPU; "
                                    "value = forward-only steps, ms_per_step = render+L1+backward+densify-stats steps",

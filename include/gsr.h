@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 5
+#define GSR_ABI_VERSION 6
 
 enum {
   GSR_OK = 0,
@@ -221,6 +221,31 @@ int gsr_dist2_knn3(const float* points, int32_t N, float* mean_dist2, void* work
  * xyz_gradient_accum += ||dL_dmeans2D.xy||, denom += 1, max_radii2D = max(max_radii2D, radii) */
 int gsr_densify_stats(int32_t P, const float* dL_dmeans2D /*[P,3]*/, const int32_t* radii,
                       float* xyz_gradient_accum, float* denom, float* max_radii2D, void* stream);
+
+/* scene/gaussian_model.py:750-772 `densify_and_prune` (plain branch: clone :580-610, split :506-578 with N = 2,
+ * postfix :466-504, prune :401-449) as one plan and one read-once / write-once pass per tensor.
+ *   gsr_densify_plan: classifies every Gaussian from xyz_gradient_accum / denom (NaN -> 0), the RAW scaling [P,3] and
+ *     RAW opacity [P]; percent_dense_extent = percent_dense * scene_extent; max_world_scale = 0.1 * extent, or < 0
+ *     when the caller's max_screen_size is None / 0 (then only the opacity test prunes, :759-764).  Synchronises the
+ *     stream and returns counts_host = {kept originals, kept clones, kept children PER COPY, split-selected}.
+ *     The output has counts[0] + counts[1] + 2*counts[2] rows in the reference's order:
+ *     [kept originals | clones | first children | second children].
+ *   gsr_densify_gather_rows: dst[rows_out, row_floats] <- src[P, row_floats]; zero_new = 1 stores zeros in the appended
+ *     rows (Adam exp_avg / exp_avg_sq of new points, :458-459).
+ *   gsr_densify_split_children: overwrites the children's rows of dst_xyz / dst_scaling with
+ *     R(rotation) (exp(scaling) * noise) + xyz and log(exp(scaling) / 1.6); noise [2*counts[3], 3] holds the standard-
+ *     normal draws of `torch.normal(mean=0, std=stds)` (:537-539) in the reference's order (all first samples of the
+ *     selected Gaussians, then all second samples). */
+size_t gsr_densify_workspace_bytes(int32_t P);
+int gsr_densify_plan(int32_t P, const float* xyz_gradient_accum, const float* denom, const float* scaling_raw,
+                     const float* opacity_raw, float grad_threshold, float percent_dense_extent, float min_opacity,
+                     float max_world_scale, void* workspace, size_t workspace_bytes, uint32_t counts_host[4],
+                     void* stream);
+int gsr_densify_gather_rows(int32_t P, int32_t row_floats, const float* src, const void* workspace,
+                            const uint32_t counts[4], int32_t zero_new, float* dst, void* stream);
+int gsr_densify_split_children(int32_t P, const float* xyz, const float* scaling_raw, const float* rotation_raw,
+                               const float* noise, const void* workspace, const uint32_t counts[4], float* dst_xyz,
+                               float* dst_scaling, void* stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class GsrParams(C.Structure):
@@ -79,6 +79,13 @@ SYMBOLS = {
     "gsr_splat2d_backward": (C.c_int, [C.c_int32] * 4 + [C.c_void_p] * 5 + [C.c_size_t] + [C.c_void_p] * 7),
     "gsr_knn3_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "gsr_dist2_knn3": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gsr_densify_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "gsr_densify_plan": (C.c_int, [C.c_int32] + [C.c_void_p] * 4 + [C.c_float] * 4 + [C.c_void_p, C.c_size_t,
+                                   C.POINTER(C.c_uint32), C.c_void_p]),
+    "gsr_densify_gather_rows": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_int32,
+                                          C.c_void_p, C.c_void_p]),
+    "gsr_densify_split_children": (C.c_int, [C.c_int32] + [C.c_void_p] * 5 + [C.POINTER(C.c_uint32), C.c_void_p,
+                                             C.c_void_p, C.c_void_p]),
     "gsr_profile_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "gsr_profile_destroy": (C.c_int, [C.c_void_p]),
     "gsr_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),

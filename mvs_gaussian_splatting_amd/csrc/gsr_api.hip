@@ -535,4 +535,48 @@ int gsr_densify_stats(int32_t P, const float* dL_dmeans2D, const int32_t* radii,
   return check(nullptr, s, "densify_stats");
 }
 
+size_t gsr_densify_workspace_bytes(int32_t P) { return P < 0 ? 0 : DensifyLayout(P).bytes; }
+int gsr_densify_plan(int32_t P, const float* xyz_gradient_accum, const float* denom, const float* scaling_raw,
+                     const float* opacity_raw, float grad_threshold, float percent_dense_extent, float min_opacity,
+                     float max_world_scale, void* workspace, size_t workspace_bytes, uint32_t counts_host[4],
+                     void* stream) {
+  if (P < 0) return fail(GSR_E_BADARG, "P < 0");
+  if (!counts_host) return fail(GSR_E_BADARG, "NULL counts_host");
+  counts_host[0] = counts_host[1] = counts_host[2] = counts_host[3] = 0;
+  if (P == 0) return 0;
+  if (!xyz_gradient_accum || !denom || !scaling_raw || !opacity_raw || !workspace) return fail(GSR_E_BADARG, "NULL input");
+  if (((uintptr_t)workspace & 255u) != 0) return fail(GSR_E_ALIGN, "workspace must be 256-byte aligned");
+  const DensifyLayout L(P);
+  if (workspace_bytes < L.bytes) return fail(GSR_E_CAPACITY, "densify workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  launch_densify_plan(P, xyz_gradient_accum, denom, scaling_raw, opacity_raw, grad_threshold, percent_dense_extent,
+                      min_opacity, max_world_scale, max_world_scale >= 0.0f ? 1 : 0, workspace, s);
+  if (int rc = check(nullptr, s, "densify_plan")) return rc;
+  GSR_HIP(hipMemcpyAsync(counts_host, static_cast<char*>(workspace) + L.totals, 16, hipMemcpyDeviceToHost, s));
+  GSR_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+int gsr_densify_gather_rows(int32_t P, int32_t row_floats, const float* src, const void* workspace,
+                            const uint32_t counts[4], int32_t zero_new, float* dst, void* stream) {
+  if (P < 0 || row_floats <= 0) return fail(GSR_E_BADARG, "bad P / row_floats");
+  if (P == 0) return 0;
+  if (!src || !workspace || !counts) return fail(GSR_E_BADARG, "NULL argument");
+  if (!dst && counts[0] + counts[1] + counts[2] > 0) return fail(GSR_E_BADARG, "NULL dst");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  launch_densify_gather_rows(P, row_floats, src, workspace, counts, zero_new, dst, s);
+  return check(nullptr, s, "densify_gather_rows");
+}
+int gsr_densify_split_children(int32_t P, const float* xyz, const float* scaling_raw, const float* rotation_raw,
+                               const float* noise, const void* workspace, const uint32_t counts[4], float* dst_xyz,
+                               float* dst_scaling, void* stream) {
+  if (P < 0) return fail(GSR_E_BADARG, "P < 0");
+  if (!counts) return fail(GSR_E_BADARG, "NULL counts");
+  if (P == 0 || counts[2] == 0) return 0;
+  if (!xyz || !scaling_raw || !rotation_raw || !noise || !workspace || !dst_xyz || !dst_scaling)
+    return fail(GSR_E_BADARG, "NULL argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  launch_densify_split_children(P, xyz, scaling_raw, rotation_raw, noise, workspace, counts, dst_xyz, dst_scaling, s);
+  return check(nullptr, s, "densify_split_children");
+}
+
 }  // extern "C"

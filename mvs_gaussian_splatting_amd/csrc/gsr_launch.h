@@ -67,6 +67,20 @@ void launch_splat2d_bwd(int N, int K, int H, int W, const float* sx, const float
                         void* ws, const float* dL_dout, float* d_sx, float* d_sy, float* d_rho, float* d_coords,
                         float* d_colours, hipStream_t s);
 
+// densify.hip.  counts = {kept originals, kept clones, kept children per copy, split-selected}
+struct DensifyLayout {
+  size_t flags, block_counts, block_offs, totals, pos, bytes;
+  int nblocks;
+  explicit DensifyLayout(int P);
+};
+void launch_densify_plan(int P, const float* accum, const float* denom, const float* scaling, const float* opacity,
+                         float thr, float pde, float min_opacity, float ws_limit, int use_ws, void* ws, hipStream_t s);
+void launch_densify_gather_rows(int P, int w, const float* src, const void* ws, const uint32_t counts[4], int zero_new,
+                                float* dst, hipStream_t s);
+void launch_densify_split_children(int P, const float* xyz, const float* scaling, const float* rotation,
+                                   const float* noise, const void* ws, const uint32_t counts[4], float* dst_xyz,
+                                   float* dst_scaling, hipStream_t s);
+
 // knn.hip
 size_t knn_workspace_bytes(int N);
 void launch_knn3(const float* pts, int N, float* mean_dist2, void* ws, hipStream_t s);

@@ -155,3 +155,41 @@ def test_c_oracle_agrees_with_pytorch_oracle(deg, use_cov):
     assert err[robust].max() <= 2e-6
     assert np.array_equal(c["n_contrib"][robust], aux["n_contrib"].numpy().astype(np.uint32)[robust])
     assert np.abs(c["final_T"] - aux["final_T"].numpy())[robust].max() <= 1e-6
+
+
+def test_densify_restatement_invariants():
+    """oracle/densify_ref.py: row order, counts, statistics reset, moment surgery, children geometry."""
+    import math
+    from oracle.densify_ref import densify_and_prune_ref, count_split_selected_ref, GROUPS
+    g = torch.Generator().manual_seed(0)
+    P = 4000
+    params = {"xyz": torch.randn(P, 3, generator=g), "f_dc": torch.randn(P, 1, 3, generator=g),
+              "f_rest": torch.randn(P, 15, 3, generator=g), "opacity": 2.5 * torch.randn(P, 1, generator=g) - 1.0,
+              "scaling": math.log(0.05) + 1.2 * torch.randn(P, 3, generator=g), "rotation": torch.randn(P, 4, generator=g)}
+    moments = {k: (torch.randn(v.shape, generator=g), torch.rand(v.shape, generator=g)) for k, v in params.items()}
+    denom = torch.randint(0, 4, (P, 1), generator=g).float()
+    accum = torch.rand(P, 1, generator=g) * 0.0006 * denom
+    radii = torch.rand(P, generator=g) * 40
+    extent, pd, thr, min_op = 5.0, 0.01, 0.0002, 0.005
+    n_sel = count_split_selected_ref(params, accum.clone(), denom, pd, thr, extent)
+    noise = torch.randn(2 * n_sel, 3, generator=g)
+    p, m, a, d, r, info = densify_and_prune_ref(params, moments, accum, denom, radii, pd, thr, min_op, extent, 20, noise)
+    n = p["xyz"].shape[0]
+    assert info["split"] == n_sel and n == P + info["cloned"] + info["split"] - info["pruned"]
+    assert all(p[k].shape[0] == n and m[k][0].shape == p[k].shape for k in GROUPS)
+    assert a.shape == (n, 1) and float(a.abs().max()) == 0 and float(d.abs().max()) == 0 and float(r.abs().max()) == 0
+    # survivors respect the prune rules; no split parent survives as-is (its scale would exceed its children's)
+    assert float(torch.sigmoid(p["opacity"]).min()) >= min_op and float(torch.exp(p["scaling"]).max()) <= 0.1 * extent
+    # kept originals come first, in order, with their moments; appended rows have zero moments
+    grads = accum / denom
+    grads[grads.isnan()] = 0
+    sc = torch.exp(params["scaling"]).max(dim=1).values
+    split = (grads.squeeze(-1) >= thr) & (sc > pd * extent)
+    prune = (torch.sigmoid(params["opacity"]).squeeze(-1) < min_op) | (sc > 0.1 * extent)
+    keep = ~split & ~prune
+    nk = int(keep.sum())
+    assert torch.equal(p["xyz"][:nk], params["xyz"][keep]) and torch.equal(m["f_rest"][0][:nk], moments["f_rest"][0][keep])
+    assert float(m["xyz"][0][nk:].abs().max()) == 0 and float(m["xyz"][1][nk:].abs().max()) == 0
+    # max_screen_size None: only the opacity rule prunes
+    p2 = densify_and_prune_ref(params, None, accum, denom, radii, pd, thr, min_op, extent, None, noise)[0]
+    assert p2["xyz"].shape[0] >= n and float(torch.exp(p2["scaling"]).max()) > 0.1 * extent
