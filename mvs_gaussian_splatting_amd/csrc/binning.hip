@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void reconstruct_keys_kernel(uint32_t R, const
 }
 
 // ------------------------------------------------------------------------------------------
-// Radix sort, one 8-bit digit per pass, three kernels per pass (no inter-workgroup waiting):
+// Radix sort, one digit of 6..9 bits per pass (sort_pass_plan), three kernels per pass (no inter-workgroup waiting):
 //   hist    : per-block digit histogram      -> hist[digit][block]
 //   rowscan : exclusive scan of every digit row over blocks, row totals -> totals[digit]
 //   scatter : stable local ranking (wave match + LDS), exchange through LDS so that each
@@ -220,26 +220,27 @@ __global__ __launch_bounds__(256) void reconstruct_keys_kernel(uint32_t R, const
 template <typename KeyT>
 __device__ inline uint32_t digit_of(KeyT k, int shift, uint32_t mask) { return (uint32_t)(k >> shift) & mask; }
 
-template <typename KeyT>
+template <typename KeyT, int BITS, int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT* __restrict__ keys, uint32_t n,
                                                                   const uint32_t* __restrict__ n_dev, int shift,
                                                                   uint32_t mask, uint32_t nblocks,
                                                                   uint32_t* __restrict__ hist) {
+  constexpr int RADIX = 1 << BITS;
   __shared__ uint32_t h[RADIX];
   if (n_dev) n = *n_dev;     // element count known only on the device (grid sized for the capacity)
   const int tid = threadIdx.x;
 #pragma unroll
   for (int d = tid; d < RADIX; d += SORT_THREADS) h[d] = 0;
   __syncthreads();
-  const uint32_t base = blockIdx.x * SORT_TILE;
-  KeyT kk[SORT_ITEMS];
+  const uint32_t base = blockIdx.x * (SORT_THREADS * ITEMS);
+  KeyT kk[ITEMS];
 #pragma unroll
-  for (int i = 0; i < SORT_ITEMS; ++i) {       // all loads in flight before the first LDS atomic
+  for (int i = 0; i < ITEMS; ++i) {       // all loads in flight before the first LDS atomic
     const uint32_t g = base + i * SORT_THREADS + tid;
     kk[i] = g < n ? keys[g] : (KeyT)0;
   }
 #pragma unroll
-  for (int i = 0; i < SORT_ITEMS; ++i) {
+  for (int i = 0; i < ITEMS; ++i) {
     const uint32_t g = base + i * SORT_THREADS + tid;
     if (g < n) atomicAdd(&h[digit_of(kk[i], shift, mask)], 1u);
   }
@@ -276,23 +277,24 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(uint32_t* __restrict
   if (tid == 0) totals[blockIdx.x] = carry_s;
 }
 
-template <typename KeyT>
+template <typename KeyT, int BITS, int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, KeyT* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, uint32_t n, const uint32_t* __restrict__ n_dev, int shift, uint32_t mask,
     uint32_t nblocks, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals) {
+  constexpr int RADIX = 1 << BITS;
   constexpr int NW = SORT_THREADS / WAVE;
   if (n_dev) n = *n_dev;
-  if (blockIdx.x * SORT_TILE >= n) return;   // block beyond the device-side count (uniform: no barrier crossed)
-  __shared__ KeyT xbuf[SORT_TILE];            // exchange buffer: keys first, then reused for the values
+  if (blockIdx.x * (SORT_THREADS * ITEMS) >= n) return;   // block beyond the device-side count (uniform: no barrier crossed)
+  __shared__ KeyT xbuf[(SORT_THREADS * ITEMS)];            // exchange buffer: keys first, then reused for the values
   __shared__ uint32_t wave_hist[NW][RADIX];   // per-wave digit counts, then exclusive wave prefixes
   __shared__ uint32_t digit_start[RADIX];     // first local slot of every digit
   __shared__ uint32_t global_base[RADIX];     // global position of the block's first item of the digit
   __shared__ uint32_t scan_tmp[NW];
 
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
-  const uint32_t base = blockIdx.x * SORT_TILE;
-  const uint32_t wbase = base + wid * (WAVE * SORT_ITEMS);
+  const uint32_t base = blockIdx.x * (SORT_THREADS * ITEMS);
+  const uint32_t wbase = base + wid * (WAVE * ITEMS);
 
 #pragma unroll
   for (int w = 0; w < NW; ++w)
@@ -300,11 +302,11 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     for (int d = tid; d < RADIX; d += SORT_THREADS) wave_hist[w][d] = 0;
   __syncthreads();
 
-  KeyT k[SORT_ITEMS];
-  uint32_t v[SORT_ITEMS];
-  uint32_t rank[SORT_ITEMS];
+  KeyT k[ITEMS];
+  uint32_t v[ITEMS];
+  uint32_t rank[ITEMS];
 #pragma unroll
-  for (int i = 0; i < SORT_ITEMS; ++i) {
+  for (int i = 0; i < ITEMS; ++i) {
     const uint32_t g = wbase + i * WAVE + lane;
     const uint32_t gc = min(g, n - 1u);       // unconditional, index-clamped loads: all in flight together
     k[i] = keys_in[gc];
@@ -315,14 +317,14 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
   // wave execute in order, so all peers read before the leader writes).
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
-  for (int i = 0; i < SORT_ITEMS; ++i) {
+  for (int i = 0; i < ITEMS; ++i) {
     const uint32_t g = wbase + i * WAVE + lane;
     const bool ok = g < n;
     const uint32_t d = digit_of(k[i], shift, mask);
     unsigned long long peers = __ballot(ok);   // padding lanes never match real ones
     if (!ok) peers = ~peers;
 #pragma unroll
-    for (int b = 0; b < RADIX_BITS; ++b) {
+    for (int b = 0; b < BITS; ++b) {
       const bool bit = (d >> b) & 1u;
       const unsigned long long bal = __ballot(bit);
       peers &= bit ? bal : ~bal;
@@ -338,26 +340,30 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
   }
   __syncthreads();
 
-  // digit totals over the 4 waves -> exclusive wave prefixes + block-wide exclusive scan.
-  // Thread t owns the BPT adjacent digits t*BPT .. t*BPT+BPT-1.
+  // digit totals over the waves -> exclusive wave prefixes + block-wide exclusive scan.
+  // Thread t owns the BPT adjacent digits t*BPT .. t*BPT+BPT-1 (threads past the last digit own none).
   {
-    constexpr int BPT = RADIX / SORT_THREADS;
+    constexpr int BPT = RADIX >= SORT_THREADS ? RADIX / SORT_THREADS : 1;
+    const bool owner = tid * BPT < RADIX;
     uint32_t dsum[BPT], tot[BPT];
     uint32_t mine = 0, tmine = 0;
 #pragma unroll
     for (int e = 0; e < BPT; ++e) {
       const int d = tid * BPT + e;
       uint32_t run = 0;
+      dsum[e] = 0; tot[e] = 0;
+      if (owner) {
 #pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        const uint32_t c = wave_hist[w][d];
-        wave_hist[w][d] = run;
-        run += c;
+        for (int w = 0; w < NW; ++w) {
+          const uint32_t c = wave_hist[w][d];
+          wave_hist[w][d] = run;
+          run += c;
+        }
+        dsum[e] = run;
+        mine += run;
+        tot[e] = totals[d];
+        tmine += tot[e];
       }
-      dsum[e] = run;
-      mine += run;
-      tot[e] = totals[d];
-      tmine += tot[e];
     }
     const uint32_t inc = wave_incl_scan_u32(mine);
     if (lane == WAVE - 1) scan_tmp[wid] = inc;
@@ -377,13 +383,15 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     for (int w = 0; w < NW; ++w)
       if (w < wid) toff += scan_tmp[w];
     uint32_t texcl = toff + t_inc - tmine;
+    if (owner) {
 #pragma unroll
-    for (int e = 0; e < BPT; ++e) {
-      const int d = tid * BPT + e;
-      digit_start[d] = excl;
-      global_base[d] = texcl + hist[(size_t)d * nblocks + blockIdx.x];
-      excl += dsum[e];
-      texcl += tot[e];
+      for (int e = 0; e < BPT; ++e) {
+        const int d = tid * BPT + e;
+        digit_start[d] = excl;
+        global_base[d] = texcl + hist[(size_t)d * nblocks + blockIdx.x];
+        excl += dsum[e];
+        texcl += tot[e];
+      }
     }
   }
   __syncthreads();
@@ -391,17 +399,17 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
   // exchange through LDS so that every digit's run leaves the block contiguously; keys and values take
   // turns in the same buffer.  local slot = digit_start + (items of the digit in earlier waves) + rank in wave
 #pragma unroll
-  for (int i = 0; i < SORT_ITEMS; ++i) {   // the rank becomes the local slot in place
+  for (int i = 0; i < ITEMS; ++i) {   // the rank becomes the local slot in place
     const uint32_t g = wbase + i * WAVE + lane;
     const uint32_t d = digit_of(k[i], shift, mask);
     rank[i] = digit_start[d] + wave_hist[wid][d] + rank[i];
     if (g < n) xbuf[rank[i]] = k[i];
   }
   __syncthreads();
-  const uint32_t count = min((uint32_t)SORT_TILE, n - base);
-  uint32_t dst[SORT_ITEMS];
+  const uint32_t count = min((uint32_t)(SORT_THREADS * ITEMS), n - base);
+  uint32_t dst[ITEMS];
 #pragma unroll
-  for (int i = 0; i < SORT_ITEMS; ++i) {
+  for (int i = 0; i < ITEMS; ++i) {
     const uint32_t s = i * SORT_THREADS + tid;
     dst[i] = 0;
     if (s < count) {
@@ -414,13 +422,13 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
   __syncthreads();
   uint32_t* xv = reinterpret_cast<uint32_t*>(xbuf);
 #pragma unroll
-  for (int i = 0; i < SORT_ITEMS; ++i) {
+  for (int i = 0; i < ITEMS; ++i) {
     const uint32_t g = wbase + i * WAVE + lane;
     if (g < n) xv[rank[i]] = v[i];
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < SORT_ITEMS; ++i) {
+  for (int i = 0; i < ITEMS; ++i) {
     const uint32_t s = i * SORT_THREADS + tid;
     if (s < count) vals_out[dst[i]] = xv[s];
   }
@@ -491,6 +499,32 @@ void launch_duplicate_with_keys(int P, int grid_x, const BinInfo* bin, const uin
                        point_offsets, keys, vals);
 }
 
+template <typename KeyT, int BITS>
+static void sort_pass(const KeyT* kin, const uint32_t* vin, KeyT* kout, uint32_t* vout, uint32_t n, const uint32_t* n_dev,
+                      int shift, int nbits, const SortLayout& L, uint32_t* hist, uint32_t* totals, hipStream_t s) {
+  const uint32_t mask = (1u << nbits) - 1u;      // nbits <= BITS: digits above the mask do not occur
+  // (8192-item tiles for 32-bit keys were measured: no gain once the digits are <= 8 bits wide)
+  constexpr int ITEMS = SORT_ITEMS;
+  const uint32_t nblocks = (n + SORT_THREADS * ITEMS - 1) / (SORT_THREADS * ITEMS);
+  (void)L;
+  hipLaunchKernelGGL((radix_hist_kernel<KeyT, BITS, ITEMS>), dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, n, n_dev, shift,
+                     mask, nblocks, hist);
+  hipLaunchKernelGGL(radix_rowscan_kernel, dim3(1 << BITS), dim3(256), 0, s, hist, nblocks, totals);
+  hipLaunchKernelGGL((radix_scatter_kernel<KeyT, BITS, ITEMS>), dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, vin, kout,
+                     vout, n, n_dev, shift, mask, nblocks, hist, totals);
+}
+
+// Digit widths of the passes.  A block scatters 4096 items: with 2^w digits a digit's run leaves the block as
+// 4096/2^w contiguous items, so narrow digits write long segments (w = 9: 32-byte fragments; w = 6..8: 64..256 bytes)
+// and need fewer ballots to rank.  The pass count is ceil(end_bit / 9) (the fewest the 9-bit kernels allow); the bits
+// are spread evenly over those passes: 32 depth bits -> 8+8+8+8, 13 tile bits -> 7+6, 45-bit keys -> 9 x 5.
+int sort_pass_plan(int end_bit, int widths[8]) {
+  const int passes = sort_passes(end_bit);
+  const int lo = end_bit / passes, extra = end_bit % passes;
+  for (int p = 0; p < passes; ++p) widths[p] = lo + (p < extra ? 1 : 0);
+  return passes;
+}
+
 // n = element count, or the capacity when n_dev (device-side count) is given
 template <typename KeyT>
 static bool sort_pairs_impl(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t* vals_b, uint32_t n, int end_bit,
@@ -499,17 +533,17 @@ static bool sort_pairs_impl(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32
   const SortLayout L(n);
   uint32_t* hist = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + L.hist);
   uint32_t* totals = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + L.totals);
-  const int passes = sort_passes(end_bit);
+  int widths[8];
+  const int passes = sort_pass_plan(end_bit, widths);
   KeyT* kin = keys_a; uint32_t* vin = vals_a; KeyT* kout = keys_b; uint32_t* vout = vals_b;
+  int shift = 0;
   for (int pass = 0; pass < passes; ++pass) {
-    const int shift = pass * RADIX_BITS;
-    const int nbits = end_bit - shift < RADIX_BITS ? end_bit - shift : RADIX_BITS;   // ignore bits >= end_bit
-    const uint32_t mask = (1u << nbits) - 1u;
-    hipLaunchKernelGGL(radix_hist_kernel<KeyT>, dim3(L.nblocks), dim3(SORT_THREADS), 0, s, kin, n, n_dev, shift, mask,
-                       L.nblocks, hist);
-    hipLaunchKernelGGL(radix_rowscan_kernel, dim3(RADIX), dim3(256), 0, s, hist, L.nblocks, totals);
-    hipLaunchKernelGGL(radix_scatter_kernel<KeyT>, dim3(L.nblocks), dim3(SORT_THREADS), 0, s, kin, vin, kout, vout, n,
-                       n_dev, shift, mask, L.nblocks, hist, totals);
+    const int w = widths[pass];
+    if (w <= 6)      sort_pass<KeyT, 6>(kin, vin, kout, vout, n, n_dev, shift, w, L, hist, totals, s);
+    else if (w == 7) sort_pass<KeyT, 7>(kin, vin, kout, vout, n, n_dev, shift, w, L, hist, totals, s);
+    else if (w == 8) sort_pass<KeyT, 8>(kin, vin, kout, vout, n, n_dev, shift, w, L, hist, totals, s);
+    else             sort_pass<KeyT, 9>(kin, vin, kout, vout, n, n_dev, shift, w, L, hist, totals, s);
+    shift += w;
     KeyT* tk = kin; kin = kout; kout = tk;
     uint32_t* tv = vin; vin = vout; vout = tv;
   }

@@ -99,7 +99,7 @@ struct ImageLayout {
 constexpr int SORT_THREADS = 512;
 constexpr int SORT_ITEMS = 8;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;   // keys per sort block
-constexpr int RADIX_BITS = 9;   // 45-bit keys at 1080p (13 tile bits + 32 depth bits) sort in 5 passes
+constexpr int RADIX_BITS = 9;   // widest digit: 45-bit keys at 1080p (13 tile bits + 32 depth bits) sort in 5 passes
 constexpr int RADIX = 1 << RADIX_BITS;
 
 struct SortLayout {

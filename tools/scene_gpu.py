@@ -10,11 +10,13 @@ from mvs_gaussian_splatting_amd.synthetic import CONFIGS, make_scene
 
 
 class GpuScene:
-    def __init__(self, cfgname="C4", P=None, view=0):
+    def __init__(self, cfgname="C4", P=None, view=0, mutate=None):
         self.cfg = cfg = CONFIGS[cfgname]
         self.dev = dev = torch.device("cuda:0")
         self.lib = _lib.load()
         model, cam, bg, target = make_scene(cfg, P=P, view=view)
+        if mutate is not None:
+            mutate(model)          # reshape the cloud (CPU tensors) before it moves to the device
         model.to(dev); cam.to(dev)
         self.model, self.cam, self.bg, self.target = model, cam, bg.to(dev), target.to(dev)
         self.W, self.H, self.P = cfg.width, cfg.height, P or cfg.P
