@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 6
+#define GSR_ABI_VERSION 7
 
 enum {
   GSR_OK = 0,
@@ -70,7 +70,7 @@ typedef struct GsrParams {
    * scene/gaussian_model.py:151-183 and their autograd): */
   const float* shs_rest;       /* NULL, or device [P,M-1,3] (16-byte aligned): then `shs` is [P,1,3] (f_dc) */
   int32_t act_flags;           /* GSR_ACT_*: inputs are RAW parameters, the activation (and its gradient) is applied here */
-  int32_t binning_mode;        /* GSR_BINNING_TWO_LEVEL (default) or GSR_BINNING_KEYS64; same value in every call of a frame */
+  int32_t binning_mode;        /* GSR_BINNING_*; same value in every call of a frame */
   uint32_t* counts_pinned;     /* NULL, or HOST-PINNED, device-accessible uint32[2] (hipHostMalloc / torch pin_memory):
                                   the scan kernel stores (num_rendered, num_visible) there and gsr_forward_preprocess
                                   waits on an event behind that kernel only, so the depth sort it has already
@@ -80,7 +80,12 @@ typedef struct GsrParams {
 enum {
   GSR_BINNING_TWO_LEVEL = 0,   /* depth-sort the visible Gaussians (u32 keys), emit instances in depth order, stable
                                   partition by tile id (u32 keys): same lists as KEYS64 for ~2.5x less sort traffic */
-  GSR_BINNING_KEYS64 = 1       /* upstream layout: duplicateWithKeys + radix sort of u64 tile<<32|depth keys */
+  GSR_BINNING_KEYS64 = 1,      /* upstream layout: duplicateWithKeys + radix sort of u64 tile<<32|depth keys */
+  GSR_BINNING_TWO_LEVEL_CULLED = 2 /* TWO_LEVEL minus the (Gaussian, tile) instances whose tile the alpha >= 1/255
+                                  ellipse provably cannot reach (rects of <= 32 tiles; exact ellipse-vs-tile test with a
+                                  safety margin): such instances are rejected pixel by pixel by the alpha test anyway,
+                                  so colour, radii and every gradient are bit-identical to the other modes; only the
+                                  internal lists (and n_contrib positions) are shorter */
 };
 
 enum {

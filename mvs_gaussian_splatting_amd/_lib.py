@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class GsrParams(C.Structure):
@@ -38,7 +38,7 @@ class GsrGrads(C.Structure):
     ]
 
 ACT_SCALE_EXP, ACT_ROT_NORMALIZE, ACT_OPACITY_SIGMOID = 1, 2, 4
-BINNING_TWO_LEVEL, BINNING_KEYS64 = 0, 1
+BINNING_TWO_LEVEL, BINNING_KEYS64, BINNING_TWO_LEVEL_CULLED = 0, 1, 2
 DSSIM_ONE_MINUS_MEAN, DSSIM_CLAMPED_HALF = 0, 1
 
 

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void unpack_geom_kernel(int P, const Geo
   __shared__ uint32_t wave_tot[PRE_BLOCK / WAVE];
   const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
   {   // upstream's point_offsets: inclusive scan of tiles_touched in index order (block level + in-block)
-    const uint32_t t = i < P ? bin[i].tiles : 0u;
+    const uint32_t t = i < P ? bin_count(bin[i].rect_wh, bin[i].mask) : 0u;
     const uint32_t inc = wave_incl_scan_u32(t);
     const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
     if (lane == WAVE - 1) wave_tot[wid] = inc;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void unpack_geom_kernel(int P, const Geo
   }
   if (i >= P) return;
   const BinInfo b = bin[i];
-  const bool vis = b.tiles != 0;
+  const bool vis = b.rect_wh != 0;      // has a GeomRec (radius > 0 and a non-empty rect)
   GeomRec g;
   if (vis) g = rec[i];
   if (xy) { xy[2 * i] = vis ? g.x : 0.f; xy[2 * i + 1] = vis ? g.y : 0.f; }
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void unpack_geom_kernel(int P, const Geo
   }
   if (rgb) { rgb[3 * i] = vis ? g.r : 0.f; rgb[3 * i + 1] = vis ? g.g : 0.f; rgb[3 * i + 2] = vis ? g.b : 0.f; }
   if (depth) depth[i] = vis ? b.depth : 0.f;
-  if (tiles) tiles[i] = b.tiles;
+  if (tiles) tiles[i] = bin_count(b.rect_wh, b.mask);
   if (rect) {
     const uint32_t x0 = b.rect_min & 0xffffu, y0 = b.rect_min >> 16;
     rect[4 * i] = vis ? x0 : 0u; rect[4 * i + 1] = vis ? y0 : 0u;

@@ -11,9 +11,8 @@ namespace gsr {
 // the preprocess kernel, so block_offs[b] (exclusive scan of the block totals) + an in-block
 // exclusive scan of `tiles` gives every Gaussian's first slot without a separate scan pass.
 // Emission order: y outer, x inner; key = tile << 32 | bits(depth); value = Gaussian index.
-// Gaussians covering more than DUP_SMALL tiles are emitted by the whole wave cooperatively.
+// Gaussians covering more than MASK_TILES tiles are emitted by the whole wave cooperatively.
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t DUP_SMALL = 16;
 
 __global__ __launch_bounds__(PRE_BLOCK) void duplicate_with_keys_kernel(int P, int grid_x,
                                                                         const BinInfo* __restrict__ bin,
@@ -27,38 +26,41 @@ __global__ __launch_bounds__(PRE_BLOCK) void duplicate_with_keys_kernel(int P, i
   const int idx = blockIdx.x * PRE_BLOCK + tid;
   BinInfo bi{0u, 0u, 0.0f, 0u};
   if (idx < P) bi = bin[idx];
-  const uint32_t inc = wave_incl_scan_u32(bi.tiles);
+  const uint32_t tiles = bin_count(bi.rect_wh, bi.mask);
+  const uint32_t inc = wave_incl_scan_u32(tiles);
   if (lane == WAVE - 1) wave_tot[wid] = inc;
   __syncthreads();
   uint32_t base = block_offs[blockIdx.x];
 #pragma unroll
   for (int w = 0; w < PRE_BLOCK / WAVE; ++w)
     if (w < wid) base += wave_tot[w];
-  const uint32_t off = base + inc - bi.tiles;   // exclusive
+  const uint32_t off = base + inc - tiles;   // exclusive
   if (idx < P) {
-    point_offsets[idx] = off + bi.tiles;        // inclusive scan, as upstream's point_offsets
+    point_offsets[idx] = off + tiles;        // inclusive scan, as upstream's point_offsets
     slot_base[idx] = off;
   }
   const uint32_t x0 = bi.rect_min & 0xffffu, y0 = bi.rect_min >> 16;
   const uint32_t w = bi.rect_wh & 0xffffu;
   const uint64_t dbits = (uint64_t)__float_as_uint(bi.depth);
 
-  if (bi.tiles && bi.tiles <= DUP_SMALL) {
-    uint32_t o = off;
+  const uint32_t area = w * (bi.rect_wh >> 16);
+  if (tiles && area <= MASK_TILES) {             // small rects: per lane, honouring the tile mask
+    uint32_t o = off, bit = 0;
     const uint32_t h = bi.rect_wh >> 16;
     for (uint32_t y = y0; y < y0 + h; ++y)
-      for (uint32_t x = x0; x < x0 + w; ++x) {
+      for (uint32_t x = x0; x < x0 + w; ++x, ++bit) {
+        if (!((bi.mask >> bit) & 1u)) continue;
         keys[o] = ((uint64_t)(y * (uint32_t)grid_x + x) << 32) | dbits;
         vals[o] = (uint32_t)idx;
         ++o;
       }
   }
-  // wave-cooperative path for large splats
-  unsigned long long big = __ballot(bi.tiles > DUP_SMALL);
+  // wave-cooperative path for large splats (every tile of the rect)
+  unsigned long long big = __ballot(area > MASK_TILES);
   while (big) {
     const int src = __ffsll((long long)big) - 1;
     big &= big - 1;
-    const uint32_t s_tiles = __shfl(bi.tiles, src, WAVE);
+    const uint32_t s_tiles = __shfl(tiles, src, WAVE);
     const uint32_t s_off = __shfl(off, src, WAVE);
     const uint32_t s_min = __shfl(bi.rect_min, src, WAVE);
     const uint32_t s_w = __shfl(w, src, WAVE);
@@ -96,9 +98,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void compact_visible_kernel(int P, const
   const int idx = blockIdx.x * PRE_BLOCK + tid;
   BinInfo bi{0u, 0u, 0.0f, 0u};
   if (idx < P) bi = bin[idx];
-  const uint32_t vis = bi.tiles != 0u;
+  const uint32_t tiles = bin_count(bi.rect_wh, bi.mask);
+  const uint32_t vis = tiles != 0u;
   const uint32_t inc = wave_incl_scan_u32(vis);
-  const uint32_t tinc = wave_incl_scan_u32(bi.tiles);
+  const uint32_t tinc = wave_incl_scan_u32(tiles);
   if (lane == WAVE - 1) { wave_tot[wid] = inc; wave_tiles[wid] = tinc; }
   __syncthreads();
   uint32_t base = block_vis_offs[blockIdx.x];
@@ -112,12 +115,12 @@ __global__ __launch_bounds__(PRE_BLOCK) void compact_visible_kernel(int P, const
     didx[o] = (uint32_t)idx;
   }
   // slot range of this Gaussian's per-instance gradient rows: index-major (any bijection works), coalesced write
-  if (idx < P) slot_base[idx] = tbase + tinc - bi.tiles;
+  if (idx < P) slot_base[idx] = tbase + tinc - tiles;
 }
 
 __global__ __launch_bounds__(PRE_BLOCK) void gather_tiles_kernel(uint32_t V, const uint32_t* __restrict__ didx,
                                                                  const BinInfo* __restrict__ bin,
-                                                                 uint32_t* __restrict__ tiles_sorted,
+                                                                 uint32_t* __restrict__ mask_sorted,
                                                                  uint2* __restrict__ rect_sorted,
                                                                  uint32_t* __restrict__ block_sums2) {
   __shared__ uint32_t wave_tot[PRE_BLOCK / WAVE];
@@ -125,8 +128,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void gather_tiles_kernel(uint32_t V, con
   uint32_t t = 0;
   if (i < V) {
     const BinInfo bi = bin[didx[i]];          // the one random gather of the binning stage
-    t = bi.tiles;
-    tiles_sorted[i] = t;
+    t = bin_count(bi.rect_wh, bi.mask);
+    mask_sorted[i] = bi.mask;
     rect_sorted[i] = make_uint2(bi.rect_min, bi.rect_wh);
   }
   const uint32_t ws = wave_reduce_add_u32(t);
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void gather_tiles_kernel(uint32_t V, con
 // the splat size (a per-Gaussian loop here ran at 0.5 TB/s).
 __global__ __launch_bounds__(PRE_BLOCK) void emit_instances_kernel(uint32_t V, int grid_x,
                                                                    const uint32_t* __restrict__ didx,
-                                                                   const uint32_t* __restrict__ tiles_sorted,
+                                                                   const uint32_t* __restrict__ mask_sorted,
                                                                    const uint2* __restrict__ rect_sorted,
                                                                    const uint32_t* __restrict__ block_offs2,
                                                                    uint32_t* __restrict__ inst_tile,
@@ -155,15 +158,17 @@ __global__ __launch_bounds__(PRE_BLOCK) void emit_instances_kernel(uint32_t V, i
   __shared__ uint32_t s_incl[PRE_BLOCK];      // inclusive scan of tiles within the block
   __shared__ uint32_t s_g[PRE_BLOCK];
   __shared__ uint32_t s_min[PRE_BLOCK];       // rect min: x | y << 16
-  __shared__ uint32_t s_w[PRE_BLOCK];         // rect width
+  __shared__ uint32_t s_wh[PRE_BLOCK];        // rect width | height << 16
+  __shared__ uint32_t s_mask[PRE_BLOCK];      // tile mask (BinInfo::mask)
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
   const uint32_t i = blockIdx.x * PRE_BLOCK + tid;
-  uint32_t g = 0, tiles = 0;
-  uint2 rr = make_uint2(0u, 1u);
+  uint32_t g = 0, tiles = 0, mask = 0;
+  uint2 rr = make_uint2(0u, 0u);
   if (i < V) {
     g = didx[i];
-    tiles = tiles_sorted[i];
+    mask = mask_sorted[i];
     rr = rect_sorted[i];
+    tiles = bin_count(rr.y, mask);
   }
   const uint32_t inc = wave_incl_scan_u32(tiles);
   if (lane == WAVE - 1) wave_tot[wid] = inc;
@@ -175,7 +180,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void emit_instances_kernel(uint32_t V, i
   s_incl[tid] = wbase + inc;
   s_g[tid] = g;
   s_min[tid] = rr.x;
-  s_w[tid] = max(rr.y & 0xffffu, 1u);
+  s_wh[tid] = rr.y;
+  s_mask[tid] = mask;
   __syncthreads();
   const uint32_t total = s_incl[PRE_BLOCK - 1];
   const uint32_t base = block_offs2[blockIdx.x];
@@ -189,8 +195,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void emit_instances_kernel(uint32_t V, i
     }
     const int j = lo;
     const uint32_t first = j ? s_incl[j - 1] : 0u;
-    const uint32_t k = o - first;                    // rank of the tile inside the rect (y outer, x inner)
-    const uint32_t w = s_w[j];
+    const uint32_t wh = s_wh[j];
+    const uint32_t k = bin_kth(wh, s_mask[j], o - first);   // tile inside the rect (y outer, x inner) of instance o - first
+    const uint32_t w = max(wh & 0xffffu, 1u);
     uint32_t q = (uint32_t)(((float)k + 0.5f) * (1.0f / (float)w));   // k / w (exact for k < 2^20)
     const uint32_t mn = s_min[j];
     const uint32_t x = (mn & 0xffffu) + (k - q * w), y = (mn >> 16) + q;

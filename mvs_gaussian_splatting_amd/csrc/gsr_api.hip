@@ -66,7 +66,8 @@ int validate(const GsrParams* p) {
   } else if (p->shs_rest) {
     return fail(GSR_E_BADARG, "shs_rest given without shs");
   }
-  if (p->binning_mode != GSR_BINNING_TWO_LEVEL && p->binning_mode != GSR_BINNING_KEYS64)
+  if (p->binning_mode != GSR_BINNING_TWO_LEVEL && p->binning_mode != GSR_BINNING_KEYS64 &&
+      p->binning_mode != GSR_BINNING_TWO_LEVEL_CULLED)
     return fail(GSR_E_BADARG, "unknown binning_mode");
   if ((p->act_flags & (GSR_ACT_SCALE_EXP | GSR_ACT_ROT_NORMALIZE)) && !p->scales)
     return fail(GSR_E_BADARG, "scale / rotation activations need the scales + rotations inputs");
@@ -172,7 +173,7 @@ int gsr_forward_preprocess(const GsrParams* p, void* geom_ws, int32_t* radii, vo
     GSR_HIP(hipEventCreateWithFlags(&counted, hipEventDisableTiming));
     GSR_HIP(hipEventRecord(counted, s));
   }
-  if (p->binning_mode == GSR_BINNING_TWO_LEVEL) {
+  if (p->binning_mode != GSR_BINNING_KEYS64) {
     // first half of the two-level binning needs no host-side count: enqueue it before the read-back so that the
     // GPU sorts while the host round-trips (compaction + 32-bit depth sort of the visible Gaussians, device-side V)
     StageTimer t(p, GSR_STAGE_SORT, s);

@@ -21,8 +21,8 @@ struct __attribute__((aligned(64))) GeomRec {
   float x, y, cxx, cxy;          // pixel-space mean, conic xx / xy
   float cyy, opacity, r, g;      // conic yy, opacity, colour
   float b, ext_x, ext_y;         // colour, conservative half-extent of the alpha >= 1/255 ellipse
-  uint32_t reserved0;            // (the per-Gaussian row slot lives in GeomLayout::slot_base: a 4-byte write into
-                                 //  these 64-byte records costs a read-modify-write of the line)
+  uint32_t tile_mask;            // which tiles of the rect hold instances (see BinInfo::mask); the per-Gaussian row slot
+                                 //  lives in GeomLayout::slot_base (a 4-byte write into these records is a line RMW)
   uint32_t rect_min;             // tile rect min: x | y << 16
   uint32_t rect_wh;              // tile rect width | height << 16
   float depth;                   // view-space z
@@ -31,12 +31,39 @@ struct __attribute__((aligned(64))) GeomRec {
 static_assert(sizeof(GeomRec) == 64, "GeomRec must be one cache line");
 
 // Compact per-Gaussian binning input (read by duplicateWithKeys without touching GeomRec).
+// mask: for rects of at most 32 tiles, bit (ty - y0) * w + (tx - x0) is set when the tile receives an instance
+// (all w*h low bits unless GSR_BINNING_TWO_LEVEL_CULLED dropped tiles the alpha >= 1/255 ellipse cannot reach);
+// larger rects always emit every tile and carry 0xffffffff.  Invisible: rect_wh = 0 and mask = 0.
 struct __attribute__((aligned(16))) BinInfo {
   uint32_t rect_min;   // x | y << 16
   uint32_t rect_wh;    // w | h << 16
   float depth;
-  uint32_t tiles;      // w*h, 0 if invisible
+  uint32_t mask;
 };
+constexpr uint32_t MASK_TILES = 32;
+// instances (tiles_touched) of a Gaussian
+__host__ __device__ inline uint32_t bin_count(uint32_t rect_wh, uint32_t mask) {
+  const uint32_t n = (rect_wh & 0xffffu) * (rect_wh >> 16);
+#if defined(__HIP_DEVICE_COMPILE__)
+  return n <= MASK_TILES ? (uint32_t)__popc(mask) : n;
+#else
+  return n <= MASK_TILES ? (uint32_t)__builtin_popcount(mask) : n;
+#endif
+}
+__host__ __device__ inline uint32_t full_mask(uint32_t n) { return n >= 32u ? 0xffffffffu : ((1u << n) - 1u); }
+// rank of rect tile `bit` among the Gaussian's instances (its gradient-row slot relative to slot_base)
+__device__ inline uint32_t bin_rank(uint32_t rect_wh, uint32_t mask, uint32_t bit) {
+  const uint32_t n = (rect_wh & 0xffffu) * (rect_wh >> 16);
+  return n <= MASK_TILES ? (uint32_t)__popc(mask & ((1u << bit) - 1u)) : bit;
+}
+// rect tile of instance k (k < bin_count)
+__device__ inline uint32_t bin_kth(uint32_t rect_wh, uint32_t mask, uint32_t k) {
+  const uint32_t n = (rect_wh & 0xffffu) * (rect_wh >> 16);
+  if (n > MASK_TILES) return k;
+  uint32_t m = mask;
+  for (uint32_t r = 0; r < k; ++r) m &= m - 1u;
+  return (uint32_t)__ffs((int)m) - 1u;
+}
 
 // Per-instance gradient row written by the compositing backward, summed per Gaussian by
 // the preprocess backward (atomic-free, bitwise reproducible).
@@ -168,6 +195,21 @@ __host__ __device__ inline int tile_bits(int tiles) {
   int b = 0;
   while ((1 << b) < tiles) ++b;   // ceil(log2 T): upstream getHigherMsb equivalent for the sort range
   return b;
+}
+
+// Smallest value of q(d) = cxx dx^2 + 2 cxy dx dy + cyy dy^2 over the rectangle [x0,x1] x [y0,y1] of
+// offsets d = p - mean (the conic is positive definite, so off-centre the minimum sits on an edge).
+__device__ inline float qmin_rect(float cxx, float cxy, float cyy, float icxx, float icyy, float dx0, float dx1,
+                                  float dy0, float dy1) {
+#pragma clang fp contract(fast)   // also inside translation units built with -ffp-contract=off: a conservative test
+  if (dx0 <= 0.0f && dx1 >= 0.0f && dy0 <= 0.0f && dy1 >= 0.0f) return 0.0f;
+  auto q = [&](float dx, float dy) { return cxx * dx * dx + 2.0f * cxy * dx * dy + cyy * dy * dy; };
+  auto cl = [](float v, float lo, float hi) { return fminf(hi, fmaxf(lo, v)); };
+  const float a = q(dx0, cl(-cxy * dx0 * icyy, dy0, dy1));
+  const float b = q(dx1, cl(-cxy * dx1 * icyy, dy0, dy1));
+  const float c = q(cl(-cxy * dy0 * icxx, dx0, dx1), dy0);
+  const float d = q(cl(-cxy * dy1 * icxx, dx0, dx1), dy1);
+  return fminf(fminf(a, b), fminf(c, d));
 }
 
 // ---- wave helpers --------------------------------------------------------------------------

@@ -194,6 +194,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
   BinInfo bi{0u, 0u, 0.0f, 0u};
   GeomRec g;
   bool vis = false;
+  int rx0 = 0, ry0 = 0, rw = 0, rh = 0;
   float px = 0.f, py = 0.f, pz = 0.f;
   Proj pr;
   pr.a = pr.c = 1.0f;
@@ -246,13 +247,14 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
             vis = true;
             radius = (int32_t)rad;
             tiles = (uint32_t)area;
+            rx0 = x0; ry0 = y0; rw = x1 - x0; rh = y1 - y0;
             g.x = mx; g.y = my;
             g.cxx = pr.c * det_inv; g.cxy = -pr.b * det_inv; g.cyy = pr.a * det_inv;
-            g.reserved0 = 0;
+            g.tile_mask = full_mask(tiles);
             g.rect_min = (uint32_t)x0 | ((uint32_t)y0 << 16);
             g.rect_wh = (uint32_t)(x1 - x0) | ((uint32_t)(y1 - y0) << 16);
             g.depth = vz;
-            bi.rect_min = g.rect_min; bi.rect_wh = g.rect_wh; bi.depth = vz; bi.tiles = tiles;
+            bi.rect_min = g.rect_min; bi.rect_wh = g.rect_wh; bi.depth = vz;
           }
         }
       }
@@ -313,6 +315,37 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
     }
     g.opacity = op; g.r = rgb[0]; g.g = rgb[1]; g.b = rgb[2];
     g.ext_x = ext_x; g.ext_y = ext_y; g.flags = flags;
+    if (p.binning_mode == GSR_BINNING_TWO_LEVEL_CULLED && tiles <= MASK_TILES) {
+      // Drop the tiles the alpha >= 1/255 ellipse cannot reach: the same two conservative tests as the compositing
+      // kernels' sub-block mask (bounding box, then exact ellipse-vs-rectangle minimum with a safety margin) on the
+      // 16x16 pixel centres of every tile of the rect.  Every pixel of a dropped tile fails the alpha test anyway.
+      uint32_t m = 0;
+      if (ext_x >= 0.0f) {
+        if (tiles == 1u) {
+          m = 1u;      // the rect is the 3-sigma box clipped to the image: a single tile is (almost) always reached
+        } else {
+          const float t = 2.0f * __logf(255.0f * op) * 1.001f + 2e-3f;
+          const float icxx = __builtin_amdgcn_rcpf(g.cxx), icyy = __builtin_amdgcn_rcpf(g.cyy);
+          // tiles of the rect the bounding box of the alpha >= 1/255 ellipse overlaps (pixel centres k*16 .. k*16+15)
+          const float inv = 1.0f / (float)TILE;
+          const int tx_lo = max(0, (int)ceilf((g.x - ext_x - 15.0f) * inv) - rx0);
+          const int tx_hi = min(rw - 1, (int)floorf((g.x + ext_x) * inv) - rx0);
+          const int ty_lo = max(0, (int)ceilf((g.y - ext_y - 15.0f) * inv) - ry0);
+          const int ty_hi = min(rh - 1, (int)floorf((g.y + ext_y) * inv) - ry0);
+          for (int ty = ty_lo; ty <= ty_hi; ++ty) {
+            const float dy0 = (float)((ry0 + ty) * TILE) - g.y;
+            for (int tx = tx_lo; tx <= tx_hi; ++tx) {
+              const float dx0 = (float)((rx0 + tx) * TILE) - g.x;
+              if (!(qmin_rect(g.cxx, g.cxy, g.cyy, icxx, icyy, dx0, dx0 + 15.0f, dy0, dy0 + 15.0f) > t))
+                m |= 1u << (ty * rw + tx);
+            }
+          }
+        }
+      }
+      g.tile_mask = m;
+      tiles = (uint32_t)__popc(m);
+    }
+    bi.mask = g.tile_mask;
     rec[idx] = g;
   }
   if (idx < p.P) {
@@ -322,7 +355,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
 
   // block total of tiles_touched -> first level of the hierarchical scan (§8 a5)
   const uint32_t ws = wave_reduce_add_u32(tiles);
-  const uint32_t wv = (uint32_t)__popcll(__ballot(vis));
+  const uint32_t wv = (uint32_t)__popcll(__ballot(tiles != 0u));   // Gaussians that enter the binning
   if (lane == 0) { wave_sums[wid] = ws; wave_vis[wid] = wv; }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -419,7 +452,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(GsrParams p, 
   if (vis) {
     const GeomRec r = rec[idx];
     // ---- (0) deterministic sum of this Gaussian's instance rows -------------------------
-    const uint32_t n = (r.rect_wh & 0xffffu) * (r.rect_wh >> 16);
+    const uint32_t n = bin_count(r.rect_wh, r.tile_mask);
     const uint32_t slot0 = slot_base[idx];
     float dcxx = 0.f, dcxy = 0.f, dcyy = 0.f;
     for (uint32_t k = 0; k < n; ++k) {

@@ -28,10 +28,10 @@ constexpr float LOG2E = 1.4426950408889634f;
 // What one lane fetches for the instance it stages (GeomRec words 0..11 and, for the backward, 12..13).
 struct Staged {
   float4 q0, q1, q2;
-  uint32_t rect_min, rect_wh;
+  uint32_t rect_min, rect_wh, slot_base;
 };
 
-// FULL = false skips word 11 (offs_excl), which the forward never reads: a dead destination register
+// FULL = false skips word 11 (tile_mask), which the forward never reads: a dead destination register
 // of an in-flight load gets recycled by the compiler and forces an early s_waitcnt vmcnt.
 template <bool FULL>
 __device__ inline void load_staged(const GeomRec* __restrict__ rec, uint32_t id, Staged& s) {
@@ -46,20 +46,6 @@ __device__ inline void load_staged(const GeomRec* __restrict__ rec, uint32_t id,
     s.q2.y = f[1];
     s.q2.z = f[2];
   }
-}
-
-// Smallest value of q(d) = cxx dx^2 + 2 cxy dx dy + cyy dy^2 over the rectangle [x0,x1] x [y0,y1] of
-// offsets d = p - mean (the conic is positive definite, so off-centre the minimum sits on an edge).
-__device__ inline float qmin_rect(float cxx, float cxy, float cyy, float icxx, float icyy, float dx0, float dx1,
-                                  float dy0, float dy1) {
-  if (dx0 <= 0.0f && dx1 >= 0.0f && dy0 <= 0.0f && dy1 >= 0.0f) return 0.0f;
-  auto q = [&](float dx, float dy) { return cxx * dx * dx + 2.0f * cxy * dx * dy + cyy * dy * dy; };
-  auto cl = [](float v, float lo, float hi) { return fminf(hi, fmaxf(lo, v)); };
-  const float a = q(dx0, cl(-cxy * dx0 * icyy, dy0, dy1));
-  const float b = q(dx1, cl(-cxy * dx1 * icyy, dy0, dy1));
-  const float c = q(cl(-cxy * dy0 * icxx, dx0, dx1), dy0);
-  const float d = q(cl(-cxy * dy1 * icxx, dx0, dx1), dy1);
-  return fminf(fminf(a, b), fminf(c, d));
 }
 
 // Which of the tile's four 8x8 sub-blocks can the Gaussian reach with alpha >= 1/255 (bit k = sub-block k).
@@ -335,13 +321,13 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, floa
 
   Staged st;
   st.q0 = st.q1 = st.q2 = make_float4(0.f, 0.f, 0.f, 0.f);
-  st.rect_min = st.rect_wh = 0;
+  st.rect_min = st.rect_wh = st.slot_base = 0;
   // unconditional, index-clamped staging loads (see the forward kernel): ids two rounds ahead,
   // records one round ahead, walking the list back to front
   auto load_id = [&](uint32_t lo, uint32_t top) { return point_list[start + min(lo + lane, top - 1)]; };
   auto load_rec = [&](uint32_t id) {
-    load_staged<false>(rec, id, st);
-    st.q2.w = __uint_as_float(slot_base[id]);
+    load_staged<true>(rec, id, st);          // q2.w = tile_mask
+    st.slot_base = slot_base[id];
     const uint2 rr = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(rec + id) + 48);
     st.rect_min = rr.x;
     st.rect_wh = rr.y;
@@ -357,10 +343,10 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, floa
   while (hi > 0) {
     const bool have = lo + lane < hi;
     const uint32_t m = have ? subblock_mask(st.q0.x, st.q0.y, st.q2.y, st.q2.z, st.q0.z, st.q0.w, st.q1.x, st.q1.y, tx0, ty0) : 0u;
-    // slot of this instance in the unsorted instance array (the order duplicateWithKeys emitted)
+    // gradient-row slot of this instance: the Gaussian's first slot + the rank of this tile among its instances
     const uint32_t rw = st.rect_wh & 0xffffu;
-    const uint32_t slot = __float_as_uint(st.q2.w) + ((uint32_t)tile_y - (st.rect_min >> 16)) * rw +
-                          ((uint32_t)tile_x - (st.rect_min & 0xffffu));
+    const uint32_t bit = ((uint32_t)tile_y - (st.rect_min >> 16)) * rw + ((uint32_t)tile_x - (st.rect_min & 0xffffu));
+    const uint32_t slot = st.slot_base + bin_rank(st.rect_wh, __float_as_uint(st.q2.w), have ? bit : 0u);
     LdsRec lr;
     make_lds(st, lr);
     __builtin_amdgcn_wave_barrier();

@@ -54,10 +54,18 @@ def _require_gpu(t: torch.Tensor) -> torch.device:
     return t.device
 
 
+_BINNING = {"keys64": _lib.BINNING_KEYS64, "two_level": _lib.BINNING_TWO_LEVEL, "culled": _lib.BINNING_TWO_LEVEL_CULLED}
+
+
 def _binning_mode() -> int:
-    """GSR_BINNING=keys64 selects upstream's 64-bit (tile, depth) key sort; default is the two-level binning."""
+    """GSR_BINNING = culled (default: two_level minus the instances whose tile the alpha >= 1/255 ellipse cannot reach;
+    colour, radii and gradients are bit-identical to the other modes) | two_level (upstream's lists via two 32-bit
+    sorts) | keys64 (upstream's 64-bit (tile, depth) key sort)."""
     import os
-    return _lib.BINNING_KEYS64 if os.environ.get("GSR_BINNING", "").lower() == "keys64" else _lib.BINNING_TWO_LEVEL
+    name = os.environ.get("GSR_BINNING", "culled").lower()
+    if name not in _BINNING:
+        raise ValueError(f"GSR_BINNING must be one of {sorted(_BINNING)}, got {name!r}")
+    return _BINNING[name]
 
 
 _pinned = __import__("threading").local()

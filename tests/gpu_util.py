@@ -35,8 +35,8 @@ def forward_with_state(dev, settings, means3D, opacities, shs=None, colors_preco
         radii = torch.zeros(P, dtype=torch.int32, device=dev)
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
         R, V = C.c_uint32(0), C.c_uint32(0)
-        if binning_mode is not None:
-            params.binning_mode = binning_mode
+        # the list-level parity tests speak about the un-culled lists unless a mode is asked for
+        params.binning_mode = _lib.BINNING_TWO_LEVEL if binning_mode is None else binning_mode
         _lib.check(lib.gsr_forward_preprocess(C.byref(params), geom.data_ptr(), radii.data_ptr(), stream, C.byref(R),
                                               C.byref(V)), "pre")
         R, V = int(R.value), int(V.value)
