@@ -197,19 +197,22 @@ __host__ __device__ inline int tile_bits(int tiles) {
   return b;
 }
 
-// Smallest value of q(d) = cxx dx^2 + 2 cxy dx dy + cyy dy^2 over the rectangle [x0,x1] x [y0,y1] of
-// offsets d = p - mean (the conic is positive definite, so off-centre the minimum sits on an edge).
+// Smallest value of q(d) = cxx dx^2 + 2 cxy dx dy + cyy dy^2 over the rectangle [x0,x1] x [y0,y1] of offsets
+// d = p - mean.  q is convex with its minimum (0) at the mean: inside the rectangle the answer is 0, otherwise the
+// segment from any point of the rectangle to the mean lowers q all the way and leaves the rectangle through an edge
+// that faces the mean -- so only the (at most two) facing edges need their 1-D minimum.
 __device__ inline float qmin_rect(float cxx, float cxy, float cyy, float icxx, float icyy, float dx0, float dx1,
                                   float dy0, float dy1) {
 #pragma clang fp contract(fast)   // also inside translation units built with -ffp-contract=off: a conservative test
-  if (dx0 <= 0.0f && dx1 >= 0.0f && dy0 <= 0.0f && dy1 >= 0.0f) return 0.0f;
-  auto q = [&](float dx, float dy) { return cxx * dx * dx + 2.0f * cxy * dx * dy + cyy * dy * dy; };
-  auto cl = [](float v, float lo, float hi) { return fminf(hi, fmaxf(lo, v)); };
-  const float a = q(dx0, cl(-cxy * dx0 * icyy, dy0, dy1));
-  const float b = q(dx1, cl(-cxy * dx1 * icyy, dy0, dy1));
-  const float c = q(cl(-cxy * dy0 * icxx, dx0, dx1), dy0);
-  const float d = q(cl(-cxy * dy1 * icxx, dx0, dx1), dy1);
-  return fminf(fminf(a, b), fminf(c, d));
+  const float xe = fminf(dx1, fmaxf(dx0, 0.0f)), ye = fminf(dy1, fmaxf(dy0, 0.0f));   // rectangle point nearest the mean
+  // vertical facing edge x = xe (exists when xe != 0): minimise over y; horizontal facing edge y = ye likewise
+  const float yv = fminf(dy1, fmaxf(dy0, -cxy * xe * icyy));
+  const float xh = fminf(dx1, fmaxf(dx0, -cxy * ye * icxx));
+  const float qv = cxx * xe * xe + (2.0f * cxy * xe + cyy * yv) * yv;
+  const float qh = cyy * ye * ye + (2.0f * cxy * ye + cxx * xh) * xh;
+  // xe == 0: the mean lies within the x-range and the vertical "edge" degenerates to the line through the mean, whose
+  // minimum over [y0,y1] is q(0, ye) >= the horizontal edge's minimum -- taking the min with it is harmless
+  return (xe == 0.0f && ye == 0.0f) ? 0.0f : fminf(xe != 0.0f ? qv : qh, ye != 0.0f ? qh : qv);
 }
 
 // ---- wave helpers --------------------------------------------------------------------------
