@@ -132,3 +132,17 @@ def test_missing_library_is_a_loud_error(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libgsr_hip.so")
     with pytest.raises(_lib.GsrError, match="HIP extension not built"):
         _lib.load()
+
+
+def test_binning_mode_selection_from_environment(monkeypatch):
+    from mvs_gaussian_splatting_amd import _lib
+    from mvs_gaussian_splatting_amd.rasterizer import _binning_mode
+    monkeypatch.delenv("GSR_BINNING", raising=False)
+    assert _binning_mode() == _lib.BINNING_TWO_LEVEL_CULLED
+    for name, val in (("keys64", _lib.BINNING_KEYS64), ("two_level", _lib.BINNING_TWO_LEVEL), ("CULLED", _lib.BINNING_TWO_LEVEL_CULLED)):
+        monkeypatch.setenv("GSR_BINNING", name)
+        assert _binning_mode() == val
+    monkeypatch.setenv("GSR_BINNING", "fastest")
+    import pytest
+    with pytest.raises(ValueError):
+        _binning_mode()

@@ -145,3 +145,23 @@ def test_culled_full_size_C4_bit_identical_and_smaller(dev, monkeypatch):
     assert b[4] < 0.8 * a[4], (a[4], b[4])
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     assert all(torch.equal(x, y) for x, y in zip(a[3], b[3]))
+
+
+def test_all_binning_modes_agree_at_4k(dev):
+    """3840x2160 (32 400 tiles: 15 tile bits -> 8+7-bit tile passes, 47-bit keys -> 6 passes in keys64 mode), 1 M
+    Gaussians: the three binning modes give the same image bit for bit; two_level and keys64 the same lists."""
+    from gpu_util import forward_with_state, product_settings
+    from mvs_gaussian_splatting_amd.synthetic import SceneConfig, make_scene
+    cfg = SceneConfig("4k", 1_000_000, 1, 3840, 2160, 2400.0, 2400.0, math.log(0.012))
+    model, cam, bg, _ = make_scene(cfg)
+    st = product_settings(cam, bg, 1, dev)
+    outs = [forward_with_state(dev, st, model.get_xyz, model.get_opacity, shs=model.get_features,
+                               scales=model.get_scaling, rotations=model.get_rotation, binning_mode=m) for m in (0, 1, 2)]
+    assert outs[0]["R"] == outs[1]["R"] > outs[2]["R"] > 0
+    assert np.array_equal(outs[0]["keys"], outs[1]["keys"]) and np.array_equal(outs[0]["point_list"], outs[1]["point_list"])
+    assert np.array_equal(outs[0]["ranges"], outs[1]["ranges"])
+    for o in outs[1:]:
+        assert torch.equal(outs[0]["color"], o["color"]) and torch.equal(outs[0]["final_T"], o["final_T"])
+        assert torch.equal(outs[0]["radii"], o["radii"])
+    k = outs[2]["keys"]
+    assert np.all(k[1:] >= k[:-1]) and int(k[-1] >> np.uint64(32)) < 240 * 135
