@@ -368,6 +368,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
 }
 
 // Exclusive scan of per-block totals; one block per array (blockIdx 0: a, 1: b); writes offs[nb] and the total.
+// Rounds of 32768 entries: every lane owns 32 contiguous entries (one 128-byte line: all 32 loads in flight at once),
+// scans them in registers, the block scans the 1024 lane sums (two barriers), and the lane writes its 32 prefixes.
 __global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t* __restrict__ sums_a,
                                                                 uint32_t* __restrict__ offs_a,
                                                                 uint32_t* __restrict__ total_a,
@@ -375,32 +377,44 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t* _
                                                                 uint32_t* __restrict__ offs_b,
                                                                 uint32_t* __restrict__ total_b, int nb,
                                                                 uint32_t* __restrict__ host_mirror) {
+  constexpr int PER = 32;
   __shared__ uint32_t wave_tot[1024 / WAVE];
-  __shared__ uint32_t carry_s;
   const uint32_t* __restrict__ block_sums = blockIdx.x == 0 ? sums_a : sums_b;
   uint32_t* __restrict__ block_offs = blockIdx.x == 0 ? offs_a : offs_b;
   uint32_t* __restrict__ total = blockIdx.x == 0 ? total_a : total_b;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < nb; base += 1024) {
-    const int i = base + tid;
-    const uint32_t v = i < nb ? block_sums[i] : 0u;
-    const uint32_t inc = wave_incl_scan_u32(v);
+  uint32_t carry = 0;
+  for (int base = 0; base < nb; base += 1024 * PER) {
+    const int lo = base + tid * PER;
+    uint32_t v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) v[k] = lo + k < nb ? block_sums[lo + k] : 0u;
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) mine += v[k];
+    const uint32_t inc = wave_incl_scan_u32(mine);
+    if (base) __syncthreads();                 // the previous round's readers of wave_tot are done
     if (lane == WAVE - 1) wave_tot[wid] = inc;
     __syncthreads();
-    uint32_t woff = 0;
-    for (int w = 0; w < wid; ++w) woff += wave_tot[w];
-    const uint32_t carry = carry_s;
-    if (i < nb) block_offs[i] = carry + woff + inc - v;
-    __syncthreads();
-    if (tid == 1023) carry_s = carry + woff + inc;
-    __syncthreads();
+    uint32_t woff = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 1024 / WAVE; ++w) {
+      const uint32_t t = wave_tot[w];
+      if (w < wid) woff += t;
+      all += t;
+    }
+    uint32_t run = carry + woff + inc - mine;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      if (lo + k < nb) block_offs[lo + k] = run;
+      run += v[k];
+    }
+    carry += all;
   }
   if (tid == 0) {
-    block_offs[nb] = carry_s;
-    *total = carry_s;
-    if (host_mirror) host_mirror[blockIdx.x] = carry_s;   // pinned host memory: visible once the kernel has completed
+    block_offs[nb] = carry;
+    *total = carry;
+    if (host_mirror) host_mirror[blockIdx.x] = carry;   // pinned host memory: visible once the kernel has completed
   }
 }
 
