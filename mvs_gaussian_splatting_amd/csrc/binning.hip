@@ -572,19 +572,19 @@ void launch_compact_visible(int P, const BinInfo* bin, const uint32_t* block_vis
     hipLaunchKernelGGL(compact_visible_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, P, bin, block_vis_offs, block_offs, slot_base,
                        dkey, didx);
 }
-void launch_gather_tiles(uint32_t V, const uint32_t* didx, const BinInfo* bin, uint32_t* tiles_sorted, uint2* rect_sorted,
+void launch_gather_tiles(uint32_t V, const uint32_t* didx, const BinInfo* bin, uint32_t* mask_sorted, uint2* rect_sorted,
                          uint32_t* block_sums2, hipStream_t s) {
   const uint32_t nb = (V + PRE_BLOCK - 1) / PRE_BLOCK;
   if (nb)
-    hipLaunchKernelGGL(gather_tiles_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, V, didx, bin, tiles_sorted, rect_sorted,
+    hipLaunchKernelGGL(gather_tiles_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, V, didx, bin, mask_sorted, rect_sorted,
                        block_sums2);
 }
-void launch_emit_instances(uint32_t V, int grid_x, const uint32_t* didx, const uint32_t* tiles_sorted,
+void launch_emit_instances(uint32_t V, int grid_x, const uint32_t* didx, const uint32_t* mask_sorted,
                            const uint2* rect_sorted, const uint32_t* block_offs2, uint32_t* inst_tile, uint32_t* inst_g,
                            hipStream_t s) {
   const uint32_t nb = (V + PRE_BLOCK - 1) / PRE_BLOCK;
   if (nb)
-    hipLaunchKernelGGL(emit_instances_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, V, grid_x, didx, tiles_sorted, rect_sorted,
+    hipLaunchKernelGGL(emit_instances_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, V, grid_x, didx, mask_sorted, rect_sorted,
                        block_offs2, inst_tile, inst_g);
 }
 void launch_reconstruct_keys(uint32_t R, const uint32_t* tile_sorted, const uint32_t* point_list, const BinInfo* bin,

@@ -249,7 +249,7 @@ int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t b
       uint32_t* itb = at<uint32_t>(bin_ws, B.itile_b);
       uint32_t* iga = at<uint32_t>(bin_ws, B.ig_a);
       uint32_t* igb = at<uint32_t>(bin_ws, B.ig_b);
-      uint32_t* tiles_sorted = at<uint32_t>(bin_ws, B.tiles_sorted);
+      uint32_t* mask_sorted = at<uint32_t>(bin_ws, B.mask_sorted);
       uint32_t* bsum2 = at<uint32_t>(bin_ws, B.bsum2);
       uint32_t* boffs2 = at<uint32_t>(bin_ws, B.boffs2);
       // depth-sorted Gaussian indices: produced by stage 1 (gsr_forward_preprocess) in the geometry workspace
@@ -257,9 +257,9 @@ int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t b
       {
         StageTimer t(p, GSR_STAGE_DUPLICATE, s);   // instances emitted in depth order
         uint2* rect_sorted = at<uint2>(bin_ws, B.rect_sorted);
-        launch_gather_tiles(V, didx_sorted, bin, tiles_sorted, rect_sorted, bsum2, s);
+        launch_gather_tiles(V, didx_sorted, bin, mask_sorted, rect_sorted, bsum2, s);
         launch_scan_block_sums(bsum2, boffs2, boffs2 + B.nblocks2 + 1, nullptr, nullptr, nullptr, (int)B.nblocks2, s);
-        launch_emit_instances(V, I.grid_x, didx_sorted, tiles_sorted, rect_sorted, boffs2, ita, iga, s);
+        launch_emit_instances(V, I.grid_x, didx_sorted, mask_sorted, rect_sorted, boffs2, ita, iga, s);
       }
       if (int rc = check(p, s, "emit_instances")) return rc;
       bool in_b;

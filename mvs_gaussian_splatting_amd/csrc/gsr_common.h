@@ -149,7 +149,7 @@ struct BinLayout {
   // mode 1
   size_t keys_a, keys_b, vals_a, vals_b;
   // mode 0
-  size_t tiles_sorted, rect_sorted, bsum2, boffs2, itile_a, itile_b, ig_a, ig_b;
+  size_t mask_sorted, rect_sorted, bsum2, boffs2, itile_a, itile_b, ig_a, ig_b;
   size_t sort, bytes;
   uint32_t nblocks2;
   __host__ __device__ BinLayout(uint32_t R, uint32_t V, int mode) {
@@ -157,7 +157,7 @@ struct BinLayout {
     nblocks2 = (uint32_t)((v + PRE_BLOCK - 1) / PRE_BLOCK);
     size_t o = 0;
     keys_a = keys_b = vals_a = vals_b = 0;
-    tiles_sorted = rect_sorted = bsum2 = boffs2 = itile_a = itile_b = ig_a = ig_b = 0;
+    mask_sorted = rect_sorted = bsum2 = boffs2 = itile_a = itile_b = ig_a = ig_b = 0;
     if (mode == 1) {
       keys_a = o; o = align_up(o + 8 * n, 256);
       keys_b = o; o = align_up(o + 8 * n, 256);
@@ -165,7 +165,7 @@ struct BinLayout {
       vals_b = o; o = align_up(o + 4 * n, 256);
       sort = o;   o = align_up(o + SortLayout((uint32_t)n).bytes, 256);
     } else {
-      tiles_sorted = o; o = align_up(o + 4 * v, 256);
+      mask_sorted = o; o = align_up(o + 4 * v, 256);
       rect_sorted = o; o = align_up(o + 8 * v, 256);
       bsum2 = o;  o = align_up(o + 4 * (size_t)(nblocks2 + 1), 256);
       boffs2 = o; o = align_up(o + 4 * (size_t)(nblocks2 + 1) + 64, 256);

@@ -31,9 +31,9 @@ void launch_identify_tile_ranges(uint32_t R, const uint64_t* keys, uint2* ranges
 void launch_build_tile_order(int tiles, const uint2* ranges, uint32_t* order, hipStream_t s);
 void launch_compact_visible(int P, const BinInfo* bin, const uint32_t* block_vis_offs, const uint32_t* block_offs,
                             uint32_t* slot_base, uint32_t* dkey, uint32_t* didx, hipStream_t s);
-void launch_gather_tiles(uint32_t V, const uint32_t* didx, const BinInfo* bin, uint32_t* tiles_sorted, uint2* rect_sorted,
+void launch_gather_tiles(uint32_t V, const uint32_t* didx, const BinInfo* bin, uint32_t* mask_sorted, uint2* rect_sorted,
                          uint32_t* block_sums2, hipStream_t s);
-void launch_emit_instances(uint32_t V, int grid_x, const uint32_t* didx, const uint32_t* tiles_sorted,
+void launch_emit_instances(uint32_t V, int grid_x, const uint32_t* didx, const uint32_t* mask_sorted,
                            const uint2* rect_sorted, const uint32_t* block_offs2, uint32_t* inst_tile, uint32_t* inst_g,
                            hipStream_t s);
 void launch_reconstruct_keys(uint32_t R, const uint32_t* tile_sorted, const uint32_t* point_list, const BinInfo* bin,
