@@ -68,7 +68,7 @@ __device__ inline uint32_t bin_kth(uint32_t rect_wh, uint32_t mask, uint32_t k) 
 // Per-instance gradient row written by the compositing backward, summed per Gaussian by
 // the preprocess backward (atomic-free, bitwise reproducible).
 struct __attribute__((aligned(16))) GradRow {
-  float dmx, dmy, dcxx, dcxy;
+  float dmx, dmy, dcxx, dcxy;   // dmx, dmy: first moments sum h*(mean - pixel); preprocess_bwd applies the conic
   float dcyy, dop, dr, dg;
   float db, pad0, pad1, pad2;
 };

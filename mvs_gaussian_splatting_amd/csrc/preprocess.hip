@@ -477,6 +477,13 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(GsrParams p, 
         dop += q.dop; dcol[0] += q.dr; dcol[1] += q.dg; dcol[2] += q.db;
       }
     }
+    {
+      // the rows carry the first moments M = sum h * (mean - pixel); the conic is the same for every tile of the
+      // Gaussian, so dL/dmean2D = -0.5 * (W, H) .* (conic M) is applied once here instead of per pixel pair
+      const float mx = dm2x, my = dm2y;
+      dm2x = -0.5f * (float)p.width * (r.cxx * mx + r.cxy * my);
+      dm2y = -0.5f * (float)p.height * (r.cxy * mx + r.cyy * my);
+    }
 
     Mat4 V, Mx;
     load_mat(p.viewmatrix, V);

@@ -295,8 +295,6 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, floa
   asm volatile("" : "+v"(pxf0), "+v"(pyf0));
   const size_t HW = (size_t)W * H;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-  // scale factors applied once per instance after the wave reduction
-  const float sc_mx = 0.5f * (float)W / LOG2E, sc_my = 0.5f * (float)H / LOG2E;
 
   // per pixel: T (running transmittance in front of the current instance), Bk = sum over the
   // instances behind of (c.dL_dpix)*alpha*T  +  T_final*(bg.dL_dpix)
@@ -373,7 +371,7 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, floa
       const float cb = sC[j];
       const uint32_t pos1 = cur_lo + (uint32_t)j + 1u;
       // per-lane partial sums over the sub-blocks; un-scaled forms (constants applied after the reduction):
-      //   g_mx = sum h*(2aq dx + bq dy), g_my = sum h*(2cq dy + bq dx), g_xx = sum h dx^2, g_xy = sum h dx dy,
+      //   g_mx = sum h dx, g_my = sum h dy (first moments), g_xx = sum h dx^2, g_xy = sum h dx dy,
       //   g_yy = sum h dy^2 with h = opacity*G*dL_dalpha;  g_op = sum G*dL_dalpha;  g_r/g/b = sum alpha*T*dL_dpix
       float g_mx = 0.f, g_my = 0.f, g_xx = 0.f, g_xy = 0.f, g_yy = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
       bool any = false;
@@ -405,8 +403,8 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, floa
             g_op += gd;
             const float h = b.y * gd;
             const float hx = h * dx, hy = h * dy;
-            g_mx = fmaf(h, t + adx, g_mx);
-            g_my = fmaf(h, fmaf(a.w, dx, cdy + cdy), g_my);
+            g_mx += hx;                                    // first moments; the conic is applied per Gaussian
+            g_my += hy;                                    // by preprocess_bwd
             g_xx = fmaf(hx, dx, g_xx);
             g_xy = fmaf(hx, dy, g_xy);
             g_yy = fmaf(hy, dy, g_yy);
@@ -421,8 +419,8 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, floa
         float* dst = reinterpret_cast<float*>(rows + sj);
         if ((lane & 15) == 0) {
           const int r = lane >> 4;
-          const float f0 = r == 0 ? sc_mx : (r == 1 ? sc_my : (r == 2 ? -0.5f : -1.0f));
-          dst[r] = s0 * f0;                                    // dmx, dmy, dcxx, dcxy
+          const float f0 = r < 2 ? 1.0f : (r == 2 ? -0.5f : -1.0f);
+          dst[r] = s0 * f0;                                    // Mx, My (first moments), dcxx, dcxy
           const float f1 = r == 0 ? -0.5f : 1.0f;
           dst[4 + r] = s1 * f1;                                // dcyy, dop, dr, dg
           if (r == 0) {
