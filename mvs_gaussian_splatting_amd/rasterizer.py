@@ -140,7 +140,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             stream = _stream(dev)
             geom = torch.empty(lib.gsr_geom_bytes(P), dtype=torch.uint8, device=dev)
             img = torch.empty(lib.gsr_image_bytes(W, H), dtype=torch.uint8, device=dev)
-            radii = torch.zeros(P, dtype=torch.int32, device=dev)
+            radii = torch.empty(P, dtype=torch.int32, device=dev)      # written for every Gaussian by the kernel
             color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
             num_rendered, num_visible = C.c_uint32(0), C.c_uint32(0)
             try:
@@ -241,7 +241,7 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
             stream = _stream(dev)
             geom = torch.empty(lib.gsr_geom_bytes(P), dtype=torch.uint8, device=dev)
             img = torch.empty(lib.gsr_image_bytes(W, H), dtype=torch.uint8, device=dev)
-            radii = torch.zeros(P, dtype=torch.int32, device=dev)
+            radii = torch.empty(P, dtype=torch.int32, device=dev)      # written for every Gaussian by the kernel
             color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
             num_rendered, num_visible = C.c_uint32(0), C.c_uint32(0)
             _lib.check(lib.gsr_forward_preprocess(C.byref(params), geom.data_ptr(), _ptr(radii), stream,

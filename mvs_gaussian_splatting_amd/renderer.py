@@ -31,6 +31,21 @@ def _can_fuse(pc, pipe, override_color) -> bool:
     return fr.dim() == 3 and fr.shape[1] == 15 and pc._features_dc.shape[1] == 1 and pc._xyz.is_cuda
 
 
+_ZEROS = {}
+
+
+def _zero_leaf(like: torch.Tensor) -> torch.Tensor:
+    """A leaf tensor of zeros shaped like ``like`` with ``requires_grad`` (its ``.grad`` is a fresh tensor per
+    backward).  The zeros are cached per (shape, dtype, device) and shared read-only between the leaves."""
+    key = (tuple(like.shape), like.dtype, like.device)
+    z = _ZEROS.get(key)
+    if z is None:
+        if len(_ZEROS) > 8:
+            _ZEROS.clear()
+        z = _ZEROS[key] = torch.zeros(like.shape, dtype=like.dtype, device=like.device)
+    return z.detach().requires_grad_(True)
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier: float = 1.0,
            override_color=None, **_fork_kwargs):
     """Render the scene; ``bg_color`` must be on the GPU.  Returns the reference's result dict
@@ -39,7 +54,9 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier:
     # zero tensor whose .grad receives dL/d(mean2D) for the densification statistics.  The reference builds it as
     # `zeros_like(...) + 0` + retain_grad() (gaussian_renderer/__init__.py:32-36); a leaf with requires_grad gets
     # its .grad populated all the same and saves a 72 MB copy kernel per frame at 6 M Gaussians.
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device)
+    # The operator never reads (or writes) its values, so every frame's leaf aliases one cached block of zeros: a
+    # fresh 72 MB memset per frame is 20 us of the 6 M-Gaussian forward.
+    screenspace_points = _zero_leaf(xyz)
 
     raster_settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height),
