@@ -463,20 +463,55 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(GsrParams p, 
     for (int k = 0; k < 48; ++k) my_row[k] = 0.0f;
   }
 
+  // ---- (0) deterministic sum of every Gaussian's instance rows -----------------------------------
+  // A lane sums its own Gaussian's rows when there are few; a splat that covers many tiles (thousands, for a large
+  // one) is summed by the whole wave -- flags are read 64 at a time and most of them are clear, because the tiles
+  // behind an opaque surface never reach the instance -- in a fixed order, so the result stays reproducible.
+  constexpr uint32_t ROWS_COOP = 64;
+  GeomRec r;
+  uint32_t n_rows = 0, slot0 = 0;
+  float dcxx = 0.f, dcxy = 0.f, dcyy = 0.f;
   if (vis) {
-    const GeomRec r = rec[idx];
-    // ---- (0) deterministic sum of this Gaussian's instance rows -------------------------
-    const uint32_t n = bin_count(r.rect_wh, r.tile_mask);
-    const uint32_t slot0 = slot_base[idx];
-    float dcxx = 0.f, dcxy = 0.f, dcyy = 0.f;
-    for (uint32_t k = 0; k < n; ++k) {
-      const uint32_t s = slot0 + k;
-      if (row_flags[s]) {
-        const GradRow q = rows[s];
-        dm2x += q.dmx; dm2y += q.dmy; dcxx += q.dcxx; dcxy += q.dcxy; dcyy += q.dcyy;
-        dop += q.dop; dcol[0] += q.dr; dcol[1] += q.dg; dcol[2] += q.db;
+    r = rec[idx];
+    n_rows = bin_count(r.rect_wh, r.tile_mask);
+    slot0 = slot_base[idx];
+    if (n_rows <= ROWS_COOP) {
+      for (uint32_t k = 0; k < n_rows; ++k) {
+        const uint32_t s = slot0 + k;
+        if (row_flags[s]) {
+          const GradRow q = rows[s];
+          dm2x += q.dmx; dm2y += q.dmy; dcxx += q.dcxx; dcxy += q.dcxy; dcyy += q.dcyy;
+          dop += q.dop; dcol[0] += q.dr; dcol[1] += q.dg; dcol[2] += q.db;
+        }
       }
     }
+  }
+  {
+    unsigned long long big = __ballot(vis && n_rows > ROWS_COOP);
+    while (big) {
+      const int src = __ffsll((long long)big) - 1;
+      big &= big - 1;
+      const uint32_t s_n = (uint32_t)__shfl((int)n_rows, src, WAVE);
+      const uint32_t s_slot = (uint32_t)__shfl((int)slot0, src, WAVE);
+      float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (uint32_t k = (uint32_t)lane; k < s_n; k += WAVE) {
+        const uint32_t s = s_slot + k;
+        if (row_flags[s]) {
+          const GradRow q = rows[s];
+          acc[0] += q.dmx; acc[1] += q.dmy; acc[2] += q.dcxx; acc[3] += q.dcxy; acc[4] += q.dcyy;
+          acc[5] += q.dop; acc[6] += q.dr; acc[7] += q.dg; acc[8] += q.db;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) acc[i] = wave_reduce_add_f32(acc[i]);
+      if (lane == src) {
+        dm2x = acc[0]; dm2y = acc[1]; dcxx = acc[2]; dcxy = acc[3]; dcyy = acc[4];
+        dop = acc[5]; dcol[0] = acc[6]; dcol[1] = acc[7]; dcol[2] = acc[8];
+      }
+    }
+  }
+
+  if (vis) {
     {
       // the rows carry the first moments M = sum h * (mean - pixel); the conic is the same for every tile of the
       // Gaussian, so dL/dmean2D = -0.5 * (W, H) .* (conic M) is applied once here instead of per pixel pair

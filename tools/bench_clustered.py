@@ -13,6 +13,8 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 2_000_000
 frac = float(sys.argv[3]) if len(sys.argv) > 3 else 0.5
 lsm = float(sys.argv[4]) if len(sys.argv) > 4 else math.log(0.02)
+tail = float(sys.argv[5]) if len(sys.argv) > 5 else 0.6
+op_shift = float(sys.argv[6]) if len(sys.argv) > 6 else -1.0
 
 
 def mutate(model):
@@ -20,8 +22,8 @@ def mutate(model):
     n = int(frac * model._xyz.shape[0])
     # a dense blob in front of the camera covering ~15 % of the frame, plus a surface-like sheet
     model._xyz[:n] = torch.randn(n, 3, generator=g) * torch.tensor([0.9, 0.6, 0.5]) + torch.tensor([0.5, -0.2, 5.0])
-    model._scaling[:] = lsm + 0.6 * torch.randn(model._scaling.shape, generator=g)
-    model._opacity[:] = 1.5 * torch.randn(model._opacity.shape, generator=g) - 1.0
+    model._scaling[:] = lsm + tail * torch.randn(model._scaling.shape, generator=g)    # heavy tail: a few huge splats
+    model._opacity[:] = 1.5 * torch.randn(model._opacity.shape, generator=g) + op_shift
 
 
 for name, mut in (("uniform", None), ("clustered", mutate)):
