@@ -82,8 +82,9 @@ enum {
                                   partition by tile id (u32 keys): same lists as KEYS64 for ~2.5x less sort traffic */
   GSR_BINNING_KEYS64 = 1,      /* upstream layout: duplicateWithKeys + radix sort of u64 tile<<32|depth keys */
   GSR_BINNING_TWO_LEVEL_CULLED = 2 /* TWO_LEVEL minus the (Gaussian, tile) instances whose tile the alpha >= 1/255
-                                  ellipse provably cannot reach (rects of <= 32 tiles; exact ellipse-vs-tile test with a
-                                  safety margin): such instances are rejected pixel by pixel by the alpha test anyway,
+                                  ellipse provably cannot reach (rects of > 32 tiles shrink to the ellipse's bounding box;
+                                  rects of <= 32 tiles get an exact per-tile ellipse test with a safety margin): such
+                                  instances are rejected pixel by pixel by the alpha test anyway,
                                   so colour, radii and every gradient are bit-identical to the other modes; only the
                                   internal lists (and n_contrib positions) are shorter */
 };

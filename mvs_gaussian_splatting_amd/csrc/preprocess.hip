@@ -254,7 +254,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
             g.rect_min = (uint32_t)x0 | ((uint32_t)y0 << 16);
             g.rect_wh = (uint32_t)(x1 - x0) | ((uint32_t)(y1 - y0) << 16);
             g.depth = vz;
-            bi.rect_min = g.rect_min; bi.rect_wh = g.rect_wh; bi.depth = vz;
+            bi.depth = vz;
           }
         }
       }
@@ -315,23 +315,44 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
     }
     g.opacity = op; g.r = rgb[0]; g.g = rgb[1]; g.b = rgb[2];
     g.ext_x = ext_x; g.ext_y = ext_y; g.flags = flags;
-    if (p.binning_mode == GSR_BINNING_TWO_LEVEL_CULLED && tiles <= MASK_TILES) {
-      // Drop the tiles the alpha >= 1/255 ellipse cannot reach: the same two conservative tests as the compositing
-      // kernels' sub-block mask (bounding box, then exact ellipse-vs-rectangle minimum with a safety margin) on the
-      // 16x16 pixel centres of every tile of the rect.  Every pixel of a dropped tile fails the alpha test anyway.
-      uint32_t m = 0;
+    if (p.binning_mode == GSR_BINNING_TWO_LEVEL_CULLED) {
+      // Drop the tiles the alpha >= 1/255 ellipse cannot reach (every pixel of such a tile fails the alpha test anyway):
+      //  1. rects of more than 32 tiles shrink to the tiles the ellipse's bounding box overlaps -- upstream's rect is a
+      //     square of 3 sqrt(lambda_max), far too tall for an elongated splat;
+      //  2. rects of at most 32 tiles (also after step 1) get a per-tile mask from the same two conservative tests the
+      //     compositing kernels apply per sub-block (bounding box, then the exact ellipse-vs-rectangle minimum with a
+      //     safety margin) on the tile's 16x16 pixel centres.
+      const float inv = 1.0f / (float)TILE;
+      int tx_lo = 0, tx_hi = -1, ty_lo = 0, ty_hi = -1;     // empty when no pixel can reach alpha >= 1/255
       if (ext_x >= 0.0f) {
-        if (tiles == 1u) {
-          m = 1u;      // the rect is the 3-sigma box clipped to the image: a single tile is (almost) always reached
+        // tile k holds the pixel centres 16k .. 16k+15
+        tx_lo = max(0, (int)ceilf((g.x - ext_x - 15.0f) * inv) - rx0);
+        tx_hi = min(rw - 1, (int)floorf((g.x + ext_x) * inv) - rx0);
+        ty_lo = max(0, (int)ceilf((g.y - ext_y - 15.0f) * inv) - ry0);
+        ty_hi = min(rh - 1, (int)floorf((g.y + ext_y) * inv) - ry0);
+      }
+      if (tiles > MASK_TILES) {
+        if (tx_hi < tx_lo || ty_hi < ty_lo) {
+          rw = rh = 1;                       // a 1x1 rect with an empty mask: no instances
+          tiles = 0;
+          g.tile_mask = 0;
         } else {
+          rx0 += tx_lo; ry0 += ty_lo;
+          rw = tx_hi - tx_lo + 1; rh = ty_hi - ty_lo + 1;
+          tx_hi -= tx_lo; ty_hi -= ty_lo; tx_lo = ty_lo = 0;
+          tiles = (uint32_t)(rw * rh);
+          g.tile_mask = full_mask(tiles);
+        }
+        g.rect_min = (uint32_t)rx0 | ((uint32_t)ry0 << 16);
+        g.rect_wh = (uint32_t)rw | ((uint32_t)rh << 16);
+      }
+      if (tiles != 0u && tiles <= MASK_TILES) {
+        uint32_t m = 0;
+        if (tiles == 1u) {
+          m = (tx_hi >= tx_lo && ty_hi >= ty_lo) ? 1u : 0u;
+        } else if (tx_hi >= tx_lo && ty_hi >= ty_lo) {
           const float t = 2.0f * __logf(255.0f * op) * 1.001f + 2e-3f;
           const float icxx = __builtin_amdgcn_rcpf(g.cxx), icyy = __builtin_amdgcn_rcpf(g.cyy);
-          // tiles of the rect the bounding box of the alpha >= 1/255 ellipse overlaps (pixel centres k*16 .. k*16+15)
-          const float inv = 1.0f / (float)TILE;
-          const int tx_lo = max(0, (int)ceilf((g.x - ext_x - 15.0f) * inv) - rx0);
-          const int tx_hi = min(rw - 1, (int)floorf((g.x + ext_x) * inv) - rx0);
-          const int ty_lo = max(0, (int)ceilf((g.y - ext_y - 15.0f) * inv) - ry0);
-          const int ty_hi = min(rh - 1, (int)floorf((g.y + ext_y) * inv) - ry0);
           for (int ty = ty_lo; ty <= ty_hi; ++ty) {
             const float dy0 = (float)((ry0 + ty) * TILE) - g.y;
             for (int tx = tx_lo; tx <= tx_hi; ++tx) {
@@ -341,10 +362,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
             }
           }
         }
+        g.tile_mask = m;
+        tiles = (uint32_t)__popc(m);
       }
-      g.tile_mask = m;
-      tiles = (uint32_t)__popc(m);
     }
+    bi.rect_min = g.rect_min; bi.rect_wh = g.rect_wh;
     bi.mask = g.tile_mask;
     rec[idx] = g;
   }
