@@ -133,7 +133,7 @@ extern "C" {
 
 int gsr_abi_version(void) { return GSR_ABI_VERSION; }
 const char* gsr_last_error(void) { return g_err.c_str(); }
-const char* gsr_build_info(void) { return "libgsr_hip gfx950 wave64 tile16 radix9 two-level-binning (HIP " __DATE__ ")"; }
+const char* gsr_build_info(void) { return "libgsr_hip gfx950 wave64 tile16 radix6-9 binning:culled|two_level|keys64 (HIP " __DATE__ ")"; }
 
 size_t gsr_geom_bytes(int32_t P) { return GeomLayout(P < 0 ? 0 : P).bytes; }
 size_t gsr_image_bytes(int32_t width, int32_t height) { return ImageLayout(width, height).bytes; }
