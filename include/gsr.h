@@ -194,7 +194,8 @@ int gsr_l1_loss_fwd_bwd(const float* x, const float* gt, size_t n, float scale, 
  *   (caller zero-fills; loss = (1-lambda)*sums[0]/n + lambda*(1 - sums[1]/n));
  * dssim_mode GSR_DSSIM_CLAMPED_HALF (the 2D script's combined_loss, 2d_gaussian_splatting.py:196-202):
  *   sums[1] += sum clamp((1-SSIM)/2, 0, 1); loss = (1-lambda)*sums[0]/n + lambda*sums[1]/n.
- * dL_dx receives the full gradient of that loss; workspace = 3*C*H*W floats (gsr_l1_dssim_workspace_bytes). */
+ * dL_dx receives the full gradient of that loss; workspace: gsr_l1_dssim_workspace_bytes (three derivative maps +
+ * one pair of partial sums per 16x16 tile; the sums are formed in a fixed order, so the value is reproducible). */
 #define GSR_DSSIM_ONE_MINUS_MEAN 0
 #define GSR_DSSIM_CLAMPED_HALF 1
 size_t gsr_l1_dssim_workspace_bytes(int32_t C, int32_t H, int32_t W);

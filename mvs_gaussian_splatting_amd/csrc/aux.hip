@@ -8,10 +8,11 @@
 namespace gsr {
 
 // loss_sum += sum |x - gt| ; dL_dx = sign(x - gt) * scale.  Streaming, 16 B per lane.
-__global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ x, const float* __restrict__ gt,
-                                                      size_t n, float scale, float* __restrict__ loss_sum,
-                                                      float* __restrict__ dL_dx) {
-  __shared__ float wsum[256 / WAVE];
+constexpr int L1_THREADS = 1024;
+__global__ __launch_bounds__(L1_THREADS) void l1_loss_kernel(const float* __restrict__ x, const float* __restrict__ gt,
+                                                             size_t n, float scale, float* __restrict__ loss_sum,
+                                                             float* __restrict__ dL_dx) {
+  __shared__ float wsum[L1_THREADS / WAVE];
   const size_t n4 = n / 4;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   float acc = 0.0f;
@@ -34,8 +35,8 @@ __global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) {
     float s = 0.0f;
 #pragma unroll
-    for (int w = 0; w < 256 / WAVE; ++w) s += wsum[w];
-    atomicAdd(loss_sum, s);
+    for (int w = 0; w < L1_THREADS / WAVE; ++w) s += wsum[w];
+    atomicAdd(loss_sum, s);     // <= 512 blocks: atomics on one address serialise at ~12 ns each
   }
 }
 
@@ -108,10 +109,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void unpack_geom_kernel(int P, const Geo
 
 void launch_l1_loss(const float* x, const float* gt, size_t n, float scale, float* loss_sum, float* dL_dx,
                     hipStream_t s) {
-  size_t blocks = (n / 4 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  size_t blocks = (n / 4 + L1_THREADS - 1) / L1_THREADS;
+  if (blocks > 512) blocks = 512;     // two 16-wave blocks per CU
   if (blocks == 0) blocks = 1;
-  hipLaunchKernelGGL(l1_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, gt, n, scale, loss_sum, dL_dx);
+  hipLaunchKernelGGL(l1_loss_kernel, dim3((unsigned)blocks), dim3(L1_THREADS), 0, s, x, gt, n, scale, loss_sum, dL_dx);
 }
 void launch_densify_stats(int P, const float* dL_dmeans2D, const int32_t* radii, float* accum, float* denom,
                           float* max_radii2D, hipStream_t s) {

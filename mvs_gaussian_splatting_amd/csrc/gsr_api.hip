@@ -457,7 +457,9 @@ int gsr_l1_loss_fwd_bwd(const float* x, const float* gt, size_t n, float scale, 
 }
 
 size_t gsr_l1_dssim_workspace_bytes(int32_t C, int32_t H, int32_t W) {
-  return (C <= 0 || H <= 0 || W <= 0) ? 0 : 3 * sizeof(float) * (size_t)C * (size_t)H * (size_t)W;
+  if (C <= 0 || H <= 0 || W <= 0) return 0;
+  const size_t blocks = (size_t)((W + 15) / 16) * (size_t)((H + 15) / 16) * (size_t)C;      // 16x16 output tiles
+  return sizeof(float) * (3 * (size_t)C * (size_t)H * (size_t)W + 2 * blocks);
 }
 int gsr_l1_dssim_loss_fwd_bwd(const float* x, const float* gt, int32_t C, int32_t H, int32_t W, float lambda_dssim,
                               int32_t dssim_mode, float* sums, float* dL_dx, void* workspace, void* stream) {

@@ -24,7 +24,7 @@ __device__ inline float halo_load(const float* __restrict__ img, int W, int H, i
 
 __global__ __launch_bounds__(SS_T * SS_T) void ssim_fwd_kernel(const float* __restrict__ X, const float* __restrict__ Y,
                                                                 int W, int H, Win11 win, float lambda, float inv_n,
-                                                                int dssim_mode, float* __restrict__ sums,
+                                                                int dssim_mode, float* __restrict__ partials,
                                                                 float* __restrict__ maps) {
   __shared__ float sx[SS_H][SS_H + 1];
   __shared__ float sy[SS_H][SS_H + 1];
@@ -94,8 +94,30 @@ __global__ __launch_bounds__(SS_T * SS_T) void ssim_fwd_kernel(const float* __re
     float a = 0.f, b = 0.f;
 #pragma unroll
     for (int w = 0; w < SS_T * SS_T / WAVE; ++w) { a += red[0][w]; b += red[1][w]; }
-    atomicAdd(&sums[0], a);
-    atomicAdd(&sums[1], b);
+    // one partial pair per block, summed in block order by ssim_sum_kernel: tens of thousands of atomics on two
+    // addresses serialise (0.6 ms at 1080p) and would make the loss value depend on the arrival order
+    const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    partials[2 * blk] = a;
+    partials[2 * blk + 1] = b;
+  }
+}
+
+// sums[0] += sum of the blocks' L1 partials, sums[1] += sum of their SSIM partials (fixed order: deterministic)
+__global__ __launch_bounds__(1024) void ssim_sum_kernel(size_t nblocks, const float* __restrict__ partials,
+                                                        float* __restrict__ sums) {
+  __shared__ float red[2][1024 / WAVE];
+  float a = 0.f, b = 0.f;
+  for (size_t i = threadIdx.x; i < nblocks; i += 1024) { a += partials[2 * i]; b += partials[2 * i + 1]; }
+  a = wave_reduce_add_f32(a);
+  b = wave_reduce_add_f32(b);
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+  if (lane == 0) { red[0][wid] = a; red[1][wid] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float sa = 0.f, sb = 0.f;
+    for (int w = 0; w < 1024 / WAVE; ++w) { sa += red[0][w]; sb += red[1][w]; }
+    sums[0] += sa;
+    sums[1] += sb;
   }
 }
 
@@ -153,8 +175,11 @@ void launch_l1_dssim(const float* x, const float* gt, int C, int H, int W, float
   (void)tot;
   const dim3 grid((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, C);
   const float inv_n = 1.0f / ((float)C * (float)H * (float)W);
-  hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(SS_T * SS_T), 0, s, x, gt, W, H, win, lambda, inv_n, dssim_mode, sums,
-                     maps);
+  float* partials = maps + 3 * (size_t)C * H * W;      // behind the three derivative maps
+  const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+  hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(SS_T * SS_T), 0, s, x, gt, W, H, win, lambda, inv_n, dssim_mode,
+                     partials, maps);
+  hipLaunchKernelGGL(ssim_sum_kernel, dim3(1), dim3(1024), 0, s, nblocks, partials, sums);
   hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(SS_T * SS_T), 0, s, x, gt, W, H, win, (1.0f - lambda) * inv_n, maps, dL_dx);
 }
 
