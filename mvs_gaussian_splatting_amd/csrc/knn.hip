@@ -1,10 +1,12 @@
 // distCUDA2 replacement: mean squared distance of every point to its 3 nearest neighbours,
 // the only other native dependency of the reference (simple_knn, an absent submodule; call site
 // scene/gaussian_model.py:21,210 -- used once per scene to initialise the scales).
-// Exact k-NN on a uniform grid: points are bucketed by cell with the stable radix sort of the rasterizer, and
-// every query grows its search cube ring by ring until the 3rd best distance is provably final (all unsearched
-// points lie at least r cells away); queries that would need more than KNN_MAX_RING rings (isolated outliers)
-// finish with a brute-force sweep.
+// Exact k-NN, robust to any density (SfM clouds are anything but uniform): the points are sorted along a Morton
+// curve (30-bit codes, the rasterizer's stable radix sort), consecutive runs of 128 sorted points form boxes and 64
+// boxes a super-box, each with its bounding box.  A query scans its own box, then walks the super-boxes, descends
+// into those whose bounding box is closer than its current 3rd-best distance, and likewise into their boxes: a box
+// that cannot hold a closer point is never opened, so the result is exact.  Boxes hold a fixed NUMBER of points, so
+// dense regions get small boxes -- a uniform grid of cells degenerates to O(n^2) there (15 s for 6 M clustered points).
 #include <float.h>
 
 #include "gsr_common.h"
@@ -12,7 +14,8 @@
 
 namespace gsr {
 
-constexpr int KNN_MAX_RING = 6;
+constexpr int KNN_BOX = 128;        // points per box
+constexpr int KNN_SUPER = 64;       // boxes per super-box
 
 __device__ inline unsigned f2ord(float f) {   // order-preserving float -> uint
   const unsigned u = __float_as_uint(f);
@@ -26,11 +29,6 @@ __host__ __device__ inline float ord2f(unsigned o) {
   float f; memcpy(&f, &u, 4); return f;
 #endif
 }
-
-struct KnnGrid {          // device-resident; written by knn_grid_kernel
-  float minx, miny, minz, inv_cell, cell;
-  int gx, gy, gz;
-};
 
 __global__ __launch_bounds__(256) void knn_bbox_kernel(const float* __restrict__ pts, int N, unsigned* __restrict__ mm) {
   unsigned lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
@@ -55,40 +53,6 @@ __global__ __launch_bounds__(256) void knn_bbox_kernel(const float* __restrict__
   }
 }
 
-__global__ void knn_grid_kernel(const unsigned* __restrict__ mm, int N, int max_dim, KnnGrid* __restrict__ g) {
-  const float lx = ord2f(mm[0]), ly = ord2f(mm[1]), lz = ord2f(mm[2]);
-  const float ex = ord2f(mm[3]) - lx, ey = ord2f(mm[4]) - ly, ez = ord2f(mm[5]) - lz;
-  const float ext = fmaxf(fmaxf(ex, ey), fmaxf(ez, 1e-20f));
-  // ~4 points per occupied cell for a volume-filling cloud, capped so that cell ids fit the ranges array
-  int res = (int)cbrtf((float)N * 0.25f);
-  res = max(1, min(res, max_dim));
-  const float cell = ext / (float)res * 1.0001f;
-  g->minx = lx; g->miny = ly; g->minz = lz;
-  g->cell = cell; g->inv_cell = 1.0f / cell;
-  g->gx = min(max_dim, (int)(ex / cell) + 1);
-  g->gy = min(max_dim, (int)(ey / cell) + 1);
-  g->gz = min(max_dim, (int)(ez / cell) + 1);
-}
-
-__device__ inline int3 cell_of(const KnnGrid& g, float x, float y, float z) {
-  int3 c;
-  c.x = min(g.gx - 1, max(0, (int)((x - g.minx) * g.inv_cell)));
-  c.y = min(g.gy - 1, max(0, (int)((y - g.miny) * g.inv_cell)));
-  c.z = min(g.gz - 1, max(0, (int)((z - g.minz) * g.inv_cell)));
-  return c;
-}
-
-__global__ __launch_bounds__(256) void knn_cell_keys_kernel(const float* __restrict__ pts, int N,
-                                                            const KnnGrid* __restrict__ gp, uint32_t* __restrict__ keys,
-                                                            uint32_t* __restrict__ vals) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N) return;
-  const KnnGrid g = *gp;
-  const int3 c = cell_of(g, pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]);
-  keys[i] = (uint32_t)((c.z * g.gy + c.y) * g.gx + c.x);
-  vals[i] = (uint32_t)i;
-}
-
 __device__ inline void keep3(float d, float* best) {
   if (d < best[2]) {
     if (d < best[1]) {
@@ -100,91 +64,172 @@ __device__ inline void keep3(float d, float* best) {
   }
 }
 
-__global__ __launch_bounds__(256) void knn_query_kernel(const float* __restrict__ pts, int N,
-                                                        const KnnGrid* __restrict__ gp,
-                                                        const uint32_t* __restrict__ sorted_idx,
-                                                        const uint2* __restrict__ ranges,
-                                                        float* __restrict__ mean_dist2) {
-  const int s = blockIdx.x * 256 + threadIdx.x;   // query in cell order: neighbouring lanes walk the same cells
-  if (s >= N) return;
-  const KnnGrid g = *gp;
-  const uint32_t self = sorted_idx[s];
-  const float px = pts[3 * (size_t)self], py = pts[3 * (size_t)self + 1], pz = pts[3 * (size_t)self + 2];
-  const int3 c = cell_of(g, px, py, pz);
-  float best[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
-  auto visit = [&](uint32_t j) {
-    if (j == self) return;
-    const float dx = pts[3 * (size_t)j] - px, dy = pts[3 * (size_t)j + 1] - py, dz = pts[3 * (size_t)j + 2] - pz;
-    keep3(dx * dx + dy * dy + dz * dz, best);
-  };
-  bool done = false;
-  const int rmax = max(g.gx, max(g.gy, g.gz));
-  for (int r = 0; r <= KNN_MAX_RING && !done; ++r) {
-    for (int dz = -r; dz <= r; ++dz) {
-      const int z = c.z + dz;
-      if (z < 0 || z >= g.gz) continue;
-      for (int dy = -r; dy <= r; ++dy) {
-        const int y = c.y + dy;
-        if (y < 0 || y >= g.gy) continue;
-        const bool face = (dz == -r || dz == r || dy == -r || dy == r);
-        for (int dx = -r; dx <= r; dx += (face ? 1 : 2 * r > 0 ? 2 * r : 1)) {   // shell only
-          const int x = c.x + dx;
-          if (x < 0 || x >= g.gx) continue;
-          const uint2 rg = ranges[(z * g.gy + y) * g.gx + x];
-          for (uint32_t k = rg.x; k < rg.y; ++k) visit(sorted_idx[k]);
-        }
-      }
+__device__ inline uint32_t spread10(uint32_t v) {   // 10 bits -> every third bit
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+__global__ __launch_bounds__(256) void knn_morton_kernel(const float* __restrict__ pts, int N,
+                                                         const unsigned* __restrict__ mm, uint32_t* __restrict__ keys,
+                                                         uint32_t* __restrict__ vals) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  uint32_t code = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float lo = ord2f(mm[a]), hi = ord2f(mm[3 + a]);
+    const float t = (pts[3 * (size_t)i + a] - lo) / fmaxf(hi - lo, 1e-30f);
+    const uint32_t q = (uint32_t)fminf(1023.0f, fmaxf(0.0f, t * 1023.0f));
+    code |= spread10(q) << a;
+  }
+  keys[i] = code;
+  vals[i] = (uint32_t)i;
+}
+
+// sorted points as (x, y, z, original index) + the bounding box of every run of KNN_BOX of them
+__global__ __launch_bounds__(KNN_BOX) void knn_boxes_kernel(const float* __restrict__ pts, int N,
+                                                            const uint32_t* __restrict__ sorted_idx,
+                                                            float4* __restrict__ spts, float* __restrict__ box_lo,
+                                                            float* __restrict__ box_hi) {
+  __shared__ float red[6][KNN_BOX / WAVE];
+  const int s = blockIdx.x * KNN_BOX + threadIdx.x;
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  if (s < N) {
+    const uint32_t i = sorted_idx[s];
+    const float x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+    spts[s] = make_float4(x, y, z, __uint_as_float(i));
+    lo[0] = hi[0] = x; lo[1] = hi[1] = y; lo[2] = hi[2] = z;
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], d, WAVE));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], d, WAVE));
     }
-    // every point outside the searched cube is at least r cells away (the query sits inside its own cell)
-    const float bound = (float)r * g.cell;
-    done = best[2] <= bound * bound || r >= rmax;
+    if ((threadIdx.x & (WAVE - 1)) == 0) { red[a][threadIdx.x / WAVE] = lo[a]; red[3 + a][threadIdx.x / WAVE] = hi[a]; }
   }
-  if (!done) {   // isolated point: exact fallback
-    best[0] = best[1] = best[2] = FLT_MAX;
-    for (int j = 0; j < N; ++j) visit((uint32_t)j);
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float l = red[threadIdx.x][0], h = red[3 + threadIdx.x][0];
+    for (int w = 1; w < KNN_BOX / WAVE; ++w) { l = fminf(l, red[threadIdx.x][w]); h = fmaxf(h, red[3 + threadIdx.x][w]); }
+    box_lo[3 * (size_t)blockIdx.x + threadIdx.x] = l;
+    box_hi[3 * (size_t)blockIdx.x + threadIdx.x] = h;
   }
-  mean_dist2[self] = (best[0] + best[1] + best[2]) / 3.0f;
 }
 
-constexpr int KNN_MAX_DIM = 160;   // 160^3 = 4.1 M cells
-
-size_t knn_workspace_bytes(int N) {
-  size_t n = N > 0 ? (size_t)N : 1, o = 0;
-  o = align_up(o + 64, 256);                                 // min/max + grid
-  o = align_up(o + 4 * n, 256) * 1;                          // keys a
-  o += align_up(4 * n, 256) * 3;                             // keys b, vals a, vals b
-  o += align_up(8 * (size_t)KNN_MAX_DIM * KNN_MAX_DIM * KNN_MAX_DIM, 256);   // cell ranges
-  o += align_up(SortLayout((uint32_t)n).bytes, 256);
-  return o;
+__global__ __launch_bounds__(KNN_SUPER) void knn_super_kernel(int nboxes, const float* __restrict__ box_lo,
+                                                              const float* __restrict__ box_hi,
+                                                              float* __restrict__ sup_lo, float* __restrict__ sup_hi) {
+  const int b = blockIdx.x * KNN_SUPER + threadIdx.x;     // one wave per super-box
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  if (b < nboxes) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { lo[a] = box_lo[3 * (size_t)b + a]; hi[a] = box_hi[3 * (size_t)b + a]; }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], d, WAVE));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], d, WAVE));
+    }
+    if (threadIdx.x == 0) { sup_lo[3 * (size_t)blockIdx.x + a] = lo[a]; sup_hi[3 * (size_t)blockIdx.x + a] = hi[a]; }
+  }
 }
+
+__device__ inline float box_dist2(const float* __restrict__ lo, const float* __restrict__ hi, float px, float py, float pz) {
+  const float dx = fmaxf(fmaxf(lo[0] - px, px - hi[0]), 0.0f);
+  const float dy = fmaxf(fmaxf(lo[1] - py, py - hi[1]), 0.0f);
+  const float dz = fmaxf(fmaxf(lo[2] - pz, pz - hi[2]), 0.0f);
+  return dx * dx + dy * dy + dz * dz;
+}
+
+__global__ __launch_bounds__(256) void knn_query_kernel(int N, int nboxes, int nsuper, const float4* __restrict__ spts,
+                                                        const float* __restrict__ box_lo, const float* __restrict__ box_hi,
+                                                        const float* __restrict__ sup_lo, const float* __restrict__ sup_hi,
+                                                        float* __restrict__ mean_dist2) {
+  const int s = blockIdx.x * 256 + threadIdx.x;   // queries in Morton order: neighbouring lanes open the same boxes
+  if (s >= N) return;
+  const float4 me = spts[s];
+  const float px = me.x, py = me.y, pz = me.z;
+  float best[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+  auto scan_box = [&](int b) {
+    const int first = b * KNN_BOX, last = min(N, first + KNN_BOX);
+    for (int j = first; j < last; ++j) {
+      if (j == s) continue;
+      const float4 q = spts[j];
+      const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
+      keep3(dx * dx + dy * dy + dz * dz, best);
+    }
+  };
+  const int own = s / KNN_BOX;
+  scan_box(own);                                   // a good bound before any pruning test
+  for (int S = 0; S < nsuper; ++S) {
+    if (!(box_dist2(sup_lo + 3 * (size_t)S, sup_hi + 3 * (size_t)S, px, py, pz) < best[2])) continue;
+    const int b0 = S * KNN_SUPER, b1 = min(nboxes, b0 + KNN_SUPER);
+    for (int b = b0; b < b1; ++b) {
+      if (b == own) continue;
+      if (box_dist2(box_lo + 3 * (size_t)b, box_hi + 3 * (size_t)b, px, py, pz) < best[2]) scan_box(b);
+    }
+  }
+  mean_dist2[__float_as_uint(me.w)] = (best[0] + best[1] + best[2]) / 3.0f;
+}
+
+struct KnnLayout {
+  size_t mm, ka, kb, va, vb, spts, box_lo, box_hi, sup_lo, sup_hi, sort, bytes;
+  int nboxes, nsuper;
+  explicit KnnLayout(int N) {
+    const size_t n = N > 0 ? (size_t)N : 1;
+    nboxes = (int)((n + KNN_BOX - 1) / KNN_BOX);
+    nsuper = (nboxes + KNN_SUPER - 1) / KNN_SUPER;
+    size_t o = 0;
+    mm = o;     o = align_up(o + 64, 256);
+    ka = o;     o = align_up(o + 4 * n, 256);
+    kb = o;     o = align_up(o + 4 * n, 256);
+    va = o;     o = align_up(o + 4 * n, 256);
+    vb = o;     o = align_up(o + 4 * n, 256);
+    spts = o;   o = align_up(o + 16 * n, 256);
+    box_lo = o; o = align_up(o + 12 * (size_t)nboxes, 256);
+    box_hi = o; o = align_up(o + 12 * (size_t)nboxes, 256);
+    sup_lo = o; o = align_up(o + 12 * (size_t)nsuper, 256);
+    sup_hi = o; o = align_up(o + 12 * (size_t)nsuper, 256);
+    sort = o;   o = align_up(o + SortLayout((uint32_t)n).bytes, 256);
+    bytes = o;
+  }
+};
+
+size_t knn_workspace_bytes(int N) { return KnnLayout(N).bytes; }
 
 void launch_knn3(const float* pts, int N, float* mean_dist2, void* ws, hipStream_t s) {
   if (N <= 0) return;
+  const KnnLayout L(N);
   char* b = static_cast<char*>(ws);
-  const size_t n = (size_t)N, a4 = align_up(4 * n, 256);
-  unsigned* mm = reinterpret_cast<unsigned*>(b);
-  KnnGrid* grid = reinterpret_cast<KnnGrid*>(b + 32);
-  size_t o = 256;
-  uint32_t* ka = reinterpret_cast<uint32_t*>(b + o); o += a4;
-  uint32_t* kb = reinterpret_cast<uint32_t*>(b + o); o += a4;
-  uint32_t* va = reinterpret_cast<uint32_t*>(b + o); o += a4;
-  uint32_t* vb = reinterpret_cast<uint32_t*>(b + o); o += a4;
-  uint2* ranges = reinterpret_cast<uint2*>(b + o);
-  const size_t cells = (size_t)KNN_MAX_DIM * KNN_MAX_DIM * KNN_MAX_DIM;
-  o += align_up(8 * cells, 256);
-  void* scratch = b + o;
-  const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-  (void)hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, s);
-  (void)hipMemsetAsync(ranges, 0, 8 * cells, s);
+  unsigned* mm = reinterpret_cast<unsigned*>(b + L.mm);
+  uint32_t* ka = reinterpret_cast<uint32_t*>(b + L.ka);
+  uint32_t* kb = reinterpret_cast<uint32_t*>(b + L.kb);
+  uint32_t* va = reinterpret_cast<uint32_t*>(b + L.va);
+  uint32_t* vb = reinterpret_cast<uint32_t*>(b + L.vb);
+  float4* spts = reinterpret_cast<float4*>(b + L.spts);
+  float* box_lo = reinterpret_cast<float*>(b + L.box_lo);
+  float* box_hi = reinterpret_cast<float*>(b + L.box_hi);
+  float* sup_lo = reinterpret_cast<float*>(b + L.sup_lo);
+  float* sup_hi = reinterpret_cast<float*>(b + L.sup_hi);
+  // min words start at 0xffffffff, max words at 0 (order-preserving uint encoding of the coordinates)
+  (void)hipMemsetAsync(mm, 0xff, 12, s);
+  (void)hipMemsetAsync(mm + 3, 0, 12, s);
   const int nb = (N + 255) / 256;
   hipLaunchKernelGGL(knn_bbox_kernel, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, s, pts, N, mm);
-  hipLaunchKernelGGL(knn_grid_kernel, dim3(1), dim3(1), 0, s, mm, N, KNN_MAX_DIM, grid);
-  hipLaunchKernelGGL(knn_cell_keys_kernel, dim3(nb), dim3(256), 0, s, pts, N, grid, ka, va);
-  int bits = 0;
-  while ((1ull << bits) < cells) ++bits;
-  const bool in_b = launch_sort_pairs_u32(ka, va, kb, vb, (uint32_t)N, bits, scratch, s);
-  launch_identify_tile_ranges_u32((uint32_t)N, in_b ? kb : ka, ranges, s);
-  hipLaunchKernelGGL(knn_query_kernel, dim3(nb), dim3(256), 0, s, pts, N, grid, in_b ? vb : va, ranges, mean_dist2);
+  hipLaunchKernelGGL(knn_morton_kernel, dim3(nb), dim3(256), 0, s, pts, N, mm, ka, va);
+  const bool in_b = launch_sort_pairs_u32(ka, va, kb, vb, (uint32_t)N, 30, b + L.sort, s);
+  hipLaunchKernelGGL(knn_boxes_kernel, dim3(L.nboxes), dim3(KNN_BOX), 0, s, pts, N, in_b ? vb : va, spts, box_lo, box_hi);
+  hipLaunchKernelGGL(knn_super_kernel, dim3(L.nsuper), dim3(KNN_SUPER), 0, s, L.nboxes, box_lo, box_hi, sup_lo, sup_hi);
+  hipLaunchKernelGGL(knn_query_kernel, dim3(nb), dim3(256), 0, s, N, L.nboxes, L.nsuper, spts, box_lo, box_hi, sup_lo,
+                     sup_hi, mean_dist2);
 }
 
 }  // namespace gsr

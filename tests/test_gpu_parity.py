@@ -497,7 +497,8 @@ def test_config_C3_masked_train_step_matches_fp64_oracle(gpu_device):
         assert e <= tol, (k, e, n_fragile)
 
 
-@pytest.mark.parametrize("N,kind", [(4, "uniform"), (1000, "uniform"), (200_000, "uniform"), (50_000, "clustered")])
+@pytest.mark.parametrize("N,kind", [(4, "uniform"), (129, "uniform"), (1000, "uniform"), (200_000, "uniform"),
+                                    (50_000, "clustered"), (400_000, "clustered"), (30_000, "duplicates")])
 def test_distCUDA2_matches_kdtree(gpu_device, N, kind):
     """exact 3-NN mean squared distance vs scipy's cKDTree (the reference's simple_knn is absent)."""
     from scipy.spatial import cKDTree
@@ -505,7 +506,11 @@ def test_distCUDA2_matches_kdtree(gpu_device, N, kind):
     g = torch.Generator().manual_seed(N)
     if kind == "uniform":
         pts = torch.rand(N, 3, generator=g) * torch.tensor([4.0, 2.0, 1.0]) - 1.0
-    else:   # dense clusters plus far outliers: exercises the ring growth and the brute-force fallback
+    elif kind == "duplicates":   # coincident points (distance 0) and a degenerate (planar) cloud
+        pts = torch.rand(N, 3, generator=g)
+        pts[:, 2] = 0.5
+        pts[N // 2:] = pts[:N - N // 2]
+    else:   # dense clusters plus far outliers: boxes of very different sizes, pruning across the whole cloud
         centres = torch.randn(20, 3, generator=g) * 5
         pts = centres[torch.randint(0, 20, (N,), generator=g)] + 0.01 * torch.randn(N, 3, generator=g)
         pts[:50] = torch.randn(50, 3, generator=g) * 200
