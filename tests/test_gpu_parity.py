@@ -612,3 +612,35 @@ def test_rare_branches_forward_and_backward_match_oracle(gpu_device, mode, monke
         assert torch.isfinite(got).all(), k
         e = float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
         assert e <= tol, (k, e, n_fragile)
+
+
+def test_debug_mode_synchronises_and_matches(gpu_device, tmp_path, monkeypatch):
+    """settings.debug (gaussian_renderer/__init__.py:54): every stage is synchronised and checked; results are the
+    same bit for bit, and a failing call leaves the upstream-style snapshot behind (README.md:143-146)."""
+    import os
+    from mvs_gaussian_splatting_amd import GaussianRasterizer, _lib
+    from gpu_util import product_settings
+    model, cam, bg, target = small_scene(P=1500, sh_degree=2, width=130, height=70)
+    dev = gpu_device
+    outs = []
+    for debug in (False, True):
+        st = product_settings(cam, bg, 2, dev, debug=debug)
+        xyz = model.get_xyz.to(dev).requires_grad_(True)
+        args = dict(means2D=torch.zeros(1500, 3, device=dev, requires_grad=True), opacities=model.get_opacity.to(dev),
+                    shs=model.get_features.to(dev), scales=model.get_scaling.to(dev), rotations=model.get_rotation.to(dev))
+        col, radii = GaussianRasterizer(st)(means3D=xyz, **args)
+        (col - target.to(dev)).abs().mean().backward()
+        outs.append((col.detach().clone(), radii.clone(), xyz.grad.clone(), args["means2D"].grad.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    # a call the library rejects (rotations not 16-byte aligned) in debug mode dumps its arguments
+    monkeypatch.chdir(tmp_path)
+    st = product_settings(cam, bg, 2, dev, debug=True)
+    rot = torch.zeros(1500 * 4 + 1, device=dev)[1:].view(1500, 4)            # 4-byte aligned view
+    rot.copy_(model.get_rotation)
+    from mvs_gaussian_splatting_amd import rasterizer as R
+    monkeypatch.setattr(R, "_f32c", lambda t, name, dev_, align16=False: t)   # skip the host-side realignment
+    with pytest.raises(_lib.GsrError):
+        GaussianRasterizer(st)(means3D=model.get_xyz.to(dev), means2D=torch.zeros(1500, 3, device=dev),
+                               opacities=model.get_opacity.to(dev), shs=model.get_features.to(dev),
+                               scales=model.get_scaling.to(dev), rotations=rot)
+    assert os.path.exists(tmp_path / "snapshot_fw.dump")
