@@ -157,7 +157,8 @@ int gsr_forward_preprocess(const GsrParams* p, void* geom_ws, int32_t* radii, vo
   {
     StageTimer t(p, GSR_STAGE_PREPROCESS_FWD, s);
     launch_preprocess_fwd(*p, at<GeomRec>(geom_ws, L.rec), at<BinInfo>(geom_ws, L.bin),
-                          at<uint32_t>(geom_ws, L.block_sums), at<uint32_t>(geom_ws, L.block_vis), radii, s);
+                          at<uint32_t>(geom_ws, L.block_sums), at<uint32_t>(geom_ws, L.block_vis), radii,
+                          at<uint32_t>(geom_ws, L.total) + 2, at<uint32_t>(geom_ws, L.big_list), s);
   }
   if (int rc = check(p, s, "preprocess_fwd")) return rc;
   uint32_t* total = at<uint32_t>(geom_ws, L.total);
@@ -326,6 +327,8 @@ int gsr_backward(const GsrParams* p, const int32_t* radii, const void* geom_ws, 
   }
   {
     StageTimer t(p, GSR_STAGE_PREPROCESS_BWD, s);
+    launch_sum_big_rows(at<uint32_t>(geom_ws, L.total) + 2, at<uint32_t>(geom_ws, L.big_list), rec,
+                        at<uint32_t>(geom_ws, L.slot_base), rows, flags, s);
     launch_preprocess_bwd(*p, radii, rec, at<uint32_t>(geom_ws, L.slot_base), rows, flags, *grads, s);
   }
   return check(p, s, "preprocess_bwd");

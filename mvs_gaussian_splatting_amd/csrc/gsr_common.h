@@ -41,6 +41,7 @@ struct __attribute__((aligned(16))) BinInfo {
   uint32_t mask;
 };
 constexpr uint32_t MASK_TILES = 32;
+constexpr uint32_t ROWS_COOP = 64;   // splats with more gradient rows than this are pre-summed by sum_big_rows_kernel
 // instances (tiles_touched) of a Gaussian
 __host__ __device__ inline uint32_t bin_count(uint32_t rect_wh, uint32_t mask) {
   const uint32_t n = (rect_wh & 0xffffu) * (rect_wh >> 16);
@@ -82,7 +83,7 @@ constexpr int PRE_BLOCK = 256;      // Gaussians per preprocess / duplicate bloc
 // ---- workspace layouts (host + device agree through these helpers) -------------------------
 struct GeomLayout {
   size_t rec, bin, offsets, slot_base, block_sums, block_offs, block_vis, block_vis_offs, total;
-  size_t dkey_a, dkey_b, didx_a, didx_b, dsort, bytes;   // depth sort of the visible Gaussians (capacity P)
+  size_t dkey_a, dkey_b, didx_a, didx_b, dsort, big_list, bytes;   // depth sort of the visible Gaussians (capacity P)
   int nblocks;
   __host__ __device__ explicit GeomLayout(int P) {
     nblocks = (P + PRE_BLOCK - 1) / PRE_BLOCK;
@@ -95,12 +96,14 @@ struct GeomLayout {
     block_offs = o; o = align_up(o + 4 * (size_t)(nblocks + 1), 256);
     block_vis = o;  o = align_up(o + 4 * (size_t)(nblocks + 1), 256);        // visible Gaussians per block
     block_vis_offs = o; o = align_up(o + 4 * (size_t)(nblocks + 1), 256);
-    total = o;      o = align_up(o + 64, 256);                               // [0] = R (instances), [1] = V (visible)
+    total = o;      o = align_up(o + 64, 256);                               // [0] = R (instances), [1] = V (visible),
+                                                                             // [2] = entries of big_list
     dkey_a = o;     o = align_up(o + 4 * (size_t)P, 256);
     dkey_b = o;     o = align_up(o + 4 * (size_t)P, 256);
     didx_a = o;     o = align_up(o + 4 * (size_t)P, 256);
     didx_b = o;     o = align_up(o + 4 * (size_t)P, 256);
     dsort = o;      o = align_up(o + 4 * (size_t)(1 << 9) * ((size_t)P / 4096 + 2) + 4096, 256);
+    big_list = o;   o = align_up(o + 4 * (size_t)P, 256);    // Gaussians with more than ROWS_COOP instances (any order)
     bytes = o;
   }
 };

@@ -6,8 +6,12 @@
 namespace gsr {
 
 // preprocess.hip
+// big_count / big_list: Gaussians with more than ROWS_COOP instances are appended (big_count is zeroed here)
 void launch_preprocess_fwd(const GsrParams& p, GeomRec* rec, BinInfo* bin, uint32_t* block_sums, uint32_t* block_vis,
-                           int32_t* radii, hipStream_t s);
+                           int32_t* radii, uint32_t* big_count, uint32_t* big_list, hipStream_t s);
+// folds the gradient rows of every listed Gaussian into its first row (wave-cooperative, fixed order)
+void launch_sum_big_rows(const uint32_t* big_count, const uint32_t* big_list, const GeomRec* rec,
+                         const uint32_t* slot_base, GradRow* rows, uint8_t* row_flags, hipStream_t s);
 // exclusive scans of up to two per-block arrays in one launch (block 0: a, block 1: b); total_x = grand total
 void launch_scan_block_sums(const uint32_t* sums_a, uint32_t* offs_a, uint32_t* total_a, const uint32_t* sums_b,
                             uint32_t* offs_b, uint32_t* total_b, int nb, hipStream_t s,

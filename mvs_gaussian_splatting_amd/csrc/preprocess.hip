@@ -182,7 +182,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
                                                                    BinInfo* __restrict__ bin,
                                                                    uint32_t* __restrict__ block_sums,
                                                                    uint32_t* __restrict__ block_vis,
-                                                                   int32_t* __restrict__ radii) {
+                                                                   int32_t* __restrict__ radii,
+                                                                   uint32_t* __restrict__ big_count,
+                                                                   uint32_t* __restrict__ big_list) {
   __shared__ uint32_t wave_sums[PRE_BLOCK / WAVE];
   __shared__ uint32_t wave_vis[PRE_BLOCK / WAVE];
   const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
@@ -369,6 +371,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
     bi.rect_min = g.rect_min; bi.rect_wh = g.rect_wh;
     bi.mask = g.tile_mask;
     rec[idx] = g;
+    // large splats are rare: their gradient rows are pre-summed cooperatively by the backward (sum_big_rows_kernel)
+    if (tiles > ROWS_COOP) big_list[atomicAdd(big_count, 1u)] = (uint32_t)idx;
   }
   if (idx < p.P) {
     radii[idx] = radius;
@@ -485,50 +489,22 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(GsrParams p, 
     for (int k = 0; k < 48; ++k) my_row[k] = 0.0f;
   }
 
-  // ---- (0) deterministic sum of every Gaussian's instance rows -----------------------------------
-  // A lane sums its own Gaussian's rows when there are few; a splat that covers many tiles (thousands, for a large
-  // one) is summed by the whole wave -- flags are read 64 at a time and most of them are clear, because the tiles
-  // behind an opaque surface never reach the instance -- in a fixed order, so the result stays reproducible.
-  constexpr uint32_t ROWS_COOP = 64;
+  // ---- (0) deterministic sum of this Gaussian's instance rows ---------------------------------------------------
+  // A splat that covers more than ROWS_COOP tiles (thousands, for a large one) was folded into its first row by
+  // sum_big_rows_kernel: a single lane walking thousands of flag bytes stalls its whole wave.
   GeomRec r;
-  uint32_t n_rows = 0, slot0 = 0;
   float dcxx = 0.f, dcxy = 0.f, dcyy = 0.f;
   if (vis) {
     r = rec[idx];
-    n_rows = bin_count(r.rect_wh, r.tile_mask);
-    slot0 = slot_base[idx];
-    if (n_rows <= ROWS_COOP) {
-      for (uint32_t k = 0; k < n_rows; ++k) {
-        const uint32_t s = slot0 + k;
-        if (row_flags[s]) {
-          const GradRow q = rows[s];
-          dm2x += q.dmx; dm2y += q.dmy; dcxx += q.dcxx; dcxy += q.dcxy; dcyy += q.dcyy;
-          dop += q.dop; dcol[0] += q.dr; dcol[1] += q.dg; dcol[2] += q.db;
-        }
-      }
-    }
-  }
-  {
-    unsigned long long big = __ballot(vis && n_rows > ROWS_COOP);
-    while (big) {
-      const int src = __ffsll((long long)big) - 1;
-      big &= big - 1;
-      const uint32_t s_n = (uint32_t)__shfl((int)n_rows, src, WAVE);
-      const uint32_t s_slot = (uint32_t)__shfl((int)slot0, src, WAVE);
-      float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      for (uint32_t k = (uint32_t)lane; k < s_n; k += WAVE) {
-        const uint32_t s = s_slot + k;
-        if (row_flags[s]) {
-          const GradRow q = rows[s];
-          acc[0] += q.dmx; acc[1] += q.dmy; acc[2] += q.dcxx; acc[3] += q.dcxy; acc[4] += q.dcyy;
-          acc[5] += q.dop; acc[6] += q.dr; acc[7] += q.dg; acc[8] += q.db;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 9; ++i) acc[i] = wave_reduce_add_f32(acc[i]);
-      if (lane == src) {
-        dm2x = acc[0]; dm2y = acc[1]; dcxx = acc[2]; dcxy = acc[3]; dcyy = acc[4];
-        dop = acc[5]; dcol[0] = acc[6]; dcol[1] = acc[7]; dcol[2] = acc[8];
+    const uint32_t n_all = bin_count(r.rect_wh, r.tile_mask);
+    const uint32_t n_rows = n_all > ROWS_COOP ? 1u : n_all;
+    const uint32_t slot0 = slot_base[idx];
+    for (uint32_t k = 0; k < n_rows; ++k) {
+      const uint32_t s = slot0 + k;
+      if (row_flags[s]) {
+        const GradRow q = rows[s];
+        dm2x += q.dmx; dm2y += q.dmy; dcxx += q.dcxx; dcxy += q.dcxy; dcyy += q.dcyy;
+        dop += q.dop; dcol[0] += q.dr; dcol[1] += q.dg; dcol[2] += q.db;
       }
     }
   }
@@ -835,15 +811,62 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(GsrParams p, 
 
 
 void launch_preprocess_fwd(const GsrParams& p, GeomRec* rec, BinInfo* bin, uint32_t* block_sums, uint32_t* block_vis,
-                           int32_t* radii, hipStream_t s) {
+                           int32_t* radii, uint32_t* big_count, uint32_t* big_list, hipStream_t s) {
+  (void)hipMemsetAsync(big_count, 0, 4, s);
   const int nb = (p.P + PRE_BLOCK - 1) / PRE_BLOCK;
   if (nb > 0)
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, p, rec, bin, block_sums, block_vis, radii);
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, p, rec, bin, block_sums, block_vis, radii,
+                       big_count, big_list);
 }
 void launch_scan_block_sums(const uint32_t* sums_a, uint32_t* offs_a, uint32_t* total_a, const uint32_t* sums_b,
                             uint32_t* offs_b, uint32_t* total_b, int nb, hipStream_t s, uint32_t* host_mirror) {
   hipLaunchKernelGGL(scan_block_sums_kernel, dim3(sums_b ? 2 : 1), dim3(1024), 0, s, sums_a, offs_a, total_a, sums_b,
                      offs_b, total_b, nb, host_mirror);
+}
+// One wave per listed Gaussian (grid-stride over the list, whose length lives on the device): flags are read 64 at
+// a time -- most are clear, the tiles behind an opaque surface never reach the instance -- flagged rows are summed in
+// a fixed lane / iteration order and the total replaces the first row.
+__global__ __launch_bounds__(256) void sum_big_rows_kernel(const uint32_t* __restrict__ big_count,
+                                                           const uint32_t* __restrict__ big_list,
+                                                           const GeomRec* __restrict__ rec,
+                                                           const uint32_t* __restrict__ slot_base,
+                                                           GradRow* __restrict__ rows, uint8_t* __restrict__ row_flags) {
+  const uint32_t count = *big_count;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const uint32_t wave = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE, nwaves = gridDim.x * (256 / WAVE);
+  for (uint32_t e = wave; e < count; e += nwaves) {
+    const uint32_t idx = big_list[e];
+    const uint2 rr = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(rec + idx) + 48);   // rect_min, rect_wh
+    const uint32_t mask = rec[idx].tile_mask;
+    const uint32_t n = bin_count(rr.y, mask), slot0 = slot_base[idx];
+    float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool any = false;
+    for (uint32_t k = (uint32_t)lane; k < n; k += WAVE) {
+      const uint32_t s = slot0 + k;
+      if (row_flags[s]) {
+        const GradRow q = rows[s];
+        any = true;
+        acc[0] += q.dmx; acc[1] += q.dmy; acc[2] += q.dcxx; acc[3] += q.dcxy; acc[4] += q.dcyy;
+        acc[5] += q.dop; acc[6] += q.dr; acc[7] += q.dg; acc[8] += q.db;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = wave_reduce_add_f32(acc[i]);
+    const bool hit = __ballot(any) != 0ull;
+    if (lane == 0) {
+      GradRow t;
+      t.dmx = acc[0]; t.dmy = acc[1]; t.dcxx = acc[2]; t.dcxy = acc[3]; t.dcyy = acc[4];
+      t.dop = acc[5]; t.dr = acc[6]; t.dg = acc[7]; t.db = acc[8];
+      t.pad0 = t.pad1 = t.pad2 = 0.f;
+      rows[slot0] = t;
+      row_flags[slot0] = hit ? 1 : 0;
+    }
+  }
+}
+
+void launch_sum_big_rows(const uint32_t* big_count, const uint32_t* big_list, const GeomRec* rec,
+                         const uint32_t* slot_base, GradRow* rows, uint8_t* row_flags, hipStream_t s) {
+  hipLaunchKernelGGL(sum_big_rows_kernel, dim3(512), dim3(256), 0, s, big_count, big_list, rec, slot_base, rows, row_flags);
 }
 void launch_preprocess_bwd(const GsrParams& p, const int32_t* radii, const GeomRec* rec, const uint32_t* slot_base,
                            const GradRow* rows, const uint8_t* row_flags, const GsrGrads& g, hipStream_t s) {

@@ -1,5 +1,5 @@
 """Per-stage device times of the raw C-ABI forward/backward on a bench config (no Python host work in
-between): python tools/kernel_bench.py [C4] [iters]."""
+between): python tools/kernel_bench.py [C4] [iters] [--fused]."""
 import sys
 
 import torch
@@ -7,9 +7,10 @@ import torch
 from mvs_gaussian_splatting_amd import _lib
 from scene_gpu import GpuScene
 
-cfg = sys.argv[1] if len(sys.argv) > 1 else "C4"
-iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-s = GpuScene(cfg)
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+cfg = args[0] if len(args) > 0 else "C4"
+iters = int(args[1]) if len(args) > 1 else 10
+s = GpuScene(cfg, fused="--fused" in sys.argv)       # --fused: raw parameters + split SH, as render() feeds them
 dL = torch.sign(torch.rand(3, s.H, s.W, device=s.dev) - 0.5) / (3 * s.H * s.W)
 for _ in range(2):
     s.forward(); s.backward(dL)

@@ -10,7 +10,7 @@ from mvs_gaussian_splatting_amd.synthetic import CONFIGS, make_scene
 
 
 class GpuScene:
-    def __init__(self, cfgname="C4", P=None, view=0, mutate=None):
+    def __init__(self, cfgname="C4", P=None, view=0, mutate=None, fused=False):
         self.cfg = cfg = CONFIGS[cfgname]
         self.dev = dev = torch.device("cuda:0")
         self.lib = _lib.load()
@@ -29,7 +29,14 @@ class GpuScene:
             self.inputs = [model.get_xyz.contiguous(), model.get_features.contiguous(), e,
                            model.get_opacity.contiguous(), model.get_scaling.contiguous(),
                            model.get_rotation.contiguous(), e]
-        self.params, self.keep = _make_params(dev, self.settings, *self.inputs)
+        self.fused = fused
+        if fused:   # raw parameters, split SH, activations inside the kernels (what render() feeds by default)
+            self.inputs = [model._xyz.contiguous(), model._features_dc.contiguous(), e, model._opacity.contiguous(),
+                           model._scaling.contiguous(), model._rotation.contiguous(), e, model._features_rest.contiguous()]
+            self.params, self.keep = _make_params(dev, self.settings, *self.inputs[:7], sh_rest=self.inputs[7],
+                                                  act_flags=_lib.ACT_SCALE_EXP | _lib.ACT_ROT_NORMALIZE | _lib.ACT_OPACITY_SIGMOID)
+        else:
+            self.params, self.keep = _make_params(dev, self.settings, *self.inputs)
         self.stream = torch.cuda.current_stream(dev).cuda_stream
         lib = self.lib
         self.geom = torch.empty(lib.gsr_geom_bytes(self.P), dtype=torch.uint8, device=dev)
@@ -56,9 +63,14 @@ class GpuScene:
         lib, dev, P = self.lib, self.dev, self.P
         if not hasattr(self, "grads"):
             new = lambda *s: torch.empty(*s, device=dev)  # noqa: E731
-            self.g = [new(P, 3), new(P, 3), new(P, 16, 3), new(P, 1), new(P, 3), new(P, 4)]
+            if self.fused:
+                self.g = [new(P, 3), new(P, 3), new(P, 1, 3), new(P, 1), new(P, 3), new(P, 4), new(P, 15, 3)]
+                rest = self.g[6].data_ptr()
+            else:
+                self.g = [new(P, 3), new(P, 3), new(P, 16, 3), new(P, 1), new(P, 3), new(P, 4)]
+                rest = None
             self.grads = _lib.GsrGrads(self.g[0].data_ptr(), self.g[1].data_ptr(), self.g[2].data_ptr(), None,
-                                       self.g[3].data_ptr(), self.g[4].data_ptr(), self.g[5].data_ptr(), None, None)
+                                       self.g[3].data_ptr(), self.g[4].data_ptr(), self.g[5].data_ptr(), None, rest)
         nb = lib.gsr_backward_bytes(P, self.R)
         if not hasattr(self, "bwd_ws") or self.bwd_ws.numel() < nb:
             self.bwd_ws = torch.empty(nb, dtype=torch.uint8, device=dev)
