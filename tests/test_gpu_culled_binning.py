@@ -147,12 +147,14 @@ def test_culled_full_size_C4_bit_identical_and_smaller(dev, monkeypatch):
     assert all(torch.equal(x, y) for x, y in zip(a[3], b[3]))
 
 
-def test_all_binning_modes_agree_at_4k(dev):
-    """3840x2160 (32 400 tiles: 15 tile bits -> 8+7-bit tile passes, 47-bit keys -> 6 passes in keys64 mode), 1 M
-    Gaussians: the three binning modes give the same image bit for bit; two_level and keys64 the same lists."""
+@pytest.mark.parametrize("W,H,P,f", [(3840, 2160, 1_000_000, 2400.0), (7680, 4320, 300_000, 4800.0), (48, 16, 5000, 30.0)])
+def test_all_binning_modes_agree_at_4k(dev, W, H, P, f):
+    """3840x2160 (32 400 tiles: 15 tile bits -> 8+7-bit tile passes, 47-bit keys -> 6 passes in keys64 mode), 7680x4320
+    (129 600 tiles, 17 bits) and a 3-tile image: the three binning modes give the same image bit for bit; two_level
+    and keys64 the same lists."""
     from gpu_util import forward_with_state, product_settings
     from mvs_gaussian_splatting_amd.synthetic import SceneConfig, make_scene
-    cfg = SceneConfig("4k", 1_000_000, 1, 3840, 2160, 2400.0, 2400.0, math.log(0.012))
+    cfg = SceneConfig("big", P, 1, W, H, f, f, math.log(0.012 if W > 100 else 0.2))
     model, cam, bg, _ = make_scene(cfg)
     st = product_settings(cam, bg, 1, dev)
     outs = [forward_with_state(dev, st, model.get_xyz, model.get_opacity, shs=model.get_features,
@@ -164,4 +166,4 @@ def test_all_binning_modes_agree_at_4k(dev):
         assert torch.equal(outs[0]["color"], o["color"]) and torch.equal(outs[0]["final_T"], o["final_T"])
         assert torch.equal(outs[0]["radii"], o["radii"])
     k = outs[2]["keys"]
-    assert np.all(k[1:] >= k[:-1]) and int(k[-1] >> np.uint64(32)) < 240 * 135
+    assert np.all(k[1:] >= k[:-1]) and int(k[-1] >> np.uint64(32)) < ((W + 15) // 16) * ((H + 15) // 16)
