@@ -413,8 +413,17 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t* _
   for (int base = 0; base < nb; base += 1024 * PER) {
     const int lo = base + tid * PER;
     uint32_t v[PER];
+    if (lo + PER <= nb) {                      // whole 128-byte line: eight 16-byte loads (the arrays are 256-byte aligned)
+      const uint4* src = reinterpret_cast<const uint4*>(block_sums + lo);
 #pragma unroll
-    for (int k = 0; k < PER; ++k) v[k] = lo + k < nb ? block_sums[lo + k] : 0u;
+      for (int k = 0; k < PER / 4; ++k) {
+        const uint4 q = src[k];
+        v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) v[k] = lo + k < nb ? block_sums[lo + k] : 0u;
+    }
     uint32_t mine = 0;
 #pragma unroll
     for (int k = 0; k < PER; ++k) mine += v[k];
@@ -430,10 +439,23 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t* _
       all += t;
     }
     uint32_t run = carry + woff + inc - mine;
+    if (lo + PER <= nb) {
+      uint4* dst = reinterpret_cast<uint4*>(block_offs + lo);
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      if (lo + k < nb) block_offs[lo + k] = run;
-      run += v[k];
+      for (int k = 0; k < PER / 4; ++k) {
+        uint4 q;
+        q.x = run; run += v[4 * k];
+        q.y = run; run += v[4 * k + 1];
+        q.z = run; run += v[4 * k + 2];
+        q.w = run; run += v[4 * k + 3];
+        dst[k] = q;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        if (lo + k < nb) block_offs[lo + k] = run;
+        run += v[k];
+      }
     }
     carry += all;
   }
