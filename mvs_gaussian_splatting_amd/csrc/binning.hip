@@ -256,32 +256,57 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT* __
   for (int d = tid; d < RADIX; d += SORT_THREADS) hist[(size_t)d * nblocks + blockIdx.x] = h[d];
 }
 
-// one block per digit row
+// one block per digit row; rounds of 2048 entries: every lane scans 8 contiguous entries in registers (two 16-byte
+// loads), the block scans the 256 lane sums, the lane writes its 8 prefixes back
 __global__ __launch_bounds__(256) void radix_rowscan_kernel(uint32_t* __restrict__ hist, uint32_t nblocks,
                                                             uint32_t* __restrict__ totals) {
+  constexpr uint32_t PER = 8;
   __shared__ uint32_t wave_tot[256 / WAVE];
-  __shared__ uint32_t carry_s;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
   uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (uint32_t b0 = 0; b0 < nblocks; b0 += 256) {
-    const uint32_t i = b0 + tid;
-    const uint32_t v = i < nblocks ? row[i] : 0u;
-    const uint32_t inc = wave_incl_scan_u32(v);
+  uint32_t carry = 0;
+  for (uint32_t b0 = 0; b0 < nblocks; b0 += 256 * PER) {
+    const uint32_t lo = b0 + (uint32_t)tid * PER;
+    uint32_t v[PER];
+    const bool full = lo + PER <= nblocks;
+    if (full) {
+      const uint4 q0 = *reinterpret_cast<const uint4*>(row + lo), q1 = *reinterpret_cast<const uint4*>(row + lo + 4);
+      v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+    } else {
+#pragma unroll
+      for (uint32_t k = 0; k < PER; ++k) v[k] = lo + k < nblocks ? row[lo + k] : 0u;
+    }
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) mine += v[k];
+    const uint32_t inc = wave_incl_scan_u32(mine);
+    if (b0) __syncthreads();
     if (lane == WAVE - 1) wave_tot[wid] = inc;
     __syncthreads();
-    uint32_t woff = 0;
+    uint32_t woff = 0, all = 0;
 #pragma unroll
-    for (int w = 0; w < 256 / WAVE; ++w)
-      if (w < wid) woff += wave_tot[w];
-    const uint32_t carry = carry_s;
-    if (i < nblocks) row[i] = carry + woff + inc - v;
-    __syncthreads();
-    if (tid == 255) carry_s = carry + woff + inc;
-    __syncthreads();
+    for (int w = 0; w < 256 / WAVE; ++w) {
+      const uint32_t t = wave_tot[w];
+      if (w < wid) woff += t;
+      all += t;
+    }
+    uint32_t run = carry + woff + inc - mine;
+    if (full) {
+      uint4 q0, q1;
+      q0.x = run; run += v[0]; q0.y = run; run += v[1]; q0.z = run; run += v[2]; q0.w = run; run += v[3];
+      q1.x = run; run += v[4]; q1.y = run; run += v[5]; q1.z = run; run += v[6]; q1.w = run; run += v[7];
+      *reinterpret_cast<uint4*>(row + lo) = q0;
+      *reinterpret_cast<uint4*>(row + lo + 4) = q1;
+    } else {
+#pragma unroll
+      for (uint32_t k = 0; k < PER; ++k) {
+        if (lo + k < nblocks) row[lo + k] = run;
+        run += v[k];
+      }
+    }
+    carry += all;
   }
-  if (tid == 0) totals[blockIdx.x] = carry_s;
+  if (tid == 0) totals[blockIdx.x] = carry;
 }
 
 template <typename KeyT, int BITS, int ITEMS>
@@ -475,26 +500,56 @@ __device__ inline uint32_t len_bucket(uint32_t len) {
   const uint32_t b = 16u + (e - 4u) * 8u + ((len >> (e - 3u)) & 7u);
   return b > 255u ? 255u : b;
 }
+// lanes of the wave that hold the same 8-bit code (the synthetic clouds put almost every tile into two or three
+// buckets: one LDS atomic per lane would serialise)
+__device__ inline unsigned long long match8(uint32_t code, bool ok) {
+  unsigned long long peers = __ballot(ok);
+  if (!ok) peers = ~peers;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const bool bit = (code >> b) & 1u;
+    const unsigned long long bal = __ballot(bit);
+    peers &= bit ? bal : ~bal;
+  }
+  return peers;
+}
 __global__ __launch_bounds__(1024) void build_tile_order_kernel(int tiles, const uint2* __restrict__ ranges,
                                                                 uint32_t* __restrict__ order) {
   __shared__ uint32_t cnt[256];
   __shared__ uint32_t base[256];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const unsigned long long lt = (1ull << lane) - 1ull;
   if (tid < 256) cnt[tid] = 0;
   __syncthreads();
-  for (int t = tid; t < tiles; t += 1024) {
-    const uint2 r = ranges[t];
-    atomicAdd(&cnt[255u - len_bucket(r.y - r.x)], 1u);
+  for (int t0 = 0; t0 < tiles; t0 += 1024) {
+    const int t = t0 + tid;
+    const bool ok = t < tiles;
+    uint32_t code = 0;
+    if (ok) { const uint2 r = ranges[t]; code = 255u - len_bucket(r.y - r.x); }
+    const unsigned long long peers = match8(code, ok);
+    if (ok && (peers & lt) == 0ull) atomicAdd(&cnt[code], (uint32_t)__popcll(peers));     // one atomic per group
   }
   __syncthreads();
-  if (tid == 0) {
-    uint32_t run = 0;
-    for (int i = 0; i < 256; ++i) { base[i] = run; run += cnt[i]; }
+  if (tid < WAVE) {     // exclusive scan of the 256 counts by one wave (4 per lane)
+    uint32_t c[4], mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { c[k] = cnt[4 * tid + k]; mine += c[k]; }
+    uint32_t run = wave_incl_scan_u32(mine) - mine;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { base[4 * tid + k] = run; run += c[k]; }
   }
   __syncthreads();
-  for (int t = tid; t < tiles; t += 1024) {
-    const uint2 r = ranges[t];
-    order[atomicAdd(&base[255u - len_bucket(r.y - r.x)], 1u)] = (uint32_t)t;
+  for (int t0 = 0; t0 < tiles; t0 += 1024) {
+    const int t = t0 + tid;
+    const bool ok = t < tiles;
+    uint32_t code = 0;
+    if (ok) { const uint2 r = ranges[t]; code = 255u - len_bucket(r.y - r.x); }
+    const unsigned long long peers = match8(code, ok);
+    uint32_t first = 0;
+    const int leader = __ffsll((long long)peers) - 1;
+    if (ok && lane == leader) first = atomicAdd(&base[code], (uint32_t)__popcll(peers));
+    first = (uint32_t)__shfl((int)first, leader, WAVE);
+    if (ok) order[first + (uint32_t)__popcll(peers & lt)] = (uint32_t)t;
   }
 }
 
