@@ -156,10 +156,10 @@ def _grads_product(dev, model, cam, bg, target, deg, use_cov=False, use_colors=N
     return {k: v.grad.detach().cpu() for k, v in leaves.items()}, col.detach().cpu()
 
 
-def _grads_oracle(model, cam, bg, target, deg, use_cov=False, use_colors=None):
+def _grads_oracle(model, cam, bg, target, deg, use_cov=False, use_colors=None, dtype=torch.float64):
     from oracle import rasterize_ref
     st = make_settings(cam, bg, deg)
-    d = torch.float64
+    d = dtype
     leaves = {}
     def leaf(name, t):
         leaves[name] = t.detach().to(d).requires_grad_(True)
@@ -644,3 +644,54 @@ def test_debug_mode_synchronises_and_matches(gpu_device, tmp_path, monkeypatch):
                                opacities=model.get_opacity.to(dev), shs=model.get_features.to(dev),
                                scales=model.get_scaling.to(dev), rotations=rot)
     assert os.path.exists(tmp_path / "snapshot_fw.dump")
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_fuzz_random_small_scenes_forward_and_backward(gpu_device, seed):
+    """Randomised configurations (image size incl. partial tiles, SH degree, scale / opacity distribution, background,
+    scale_modifier, view, binning mode): integers exact, robust pixels 1e-5, gradients vs float64 autograd."""
+    from gpu_util import forward_with_state, product_settings
+    from mvs_gaussian_splatting_amd.synthetic import SceneConfig, make_scene
+    from oracle import rasterize_ref
+    rng = np.random.default_rng(1000 + seed)
+    W, H = int(rng.integers(17, 260)), int(rng.integers(17, 200))
+    deg = int(rng.integers(0, 4))
+    P = int(rng.integers(50, 2500))
+    f = float(rng.uniform(40.0, 260.0))
+    scale = float(np.exp(rng.uniform(np.log(0.01), np.log(0.4))))
+    smod = float(rng.choice([1.0, 1.0, 0.6, 1.7]))
+    mode = int(rng.integers(0, 3))
+    cfg = SceneConfig("fuzz", P, deg, W, H, f, f * float(rng.uniform(0.8, 1.25)), math.log(scale))
+    model, cam, _, target = make_scene(cfg, seed=seed, view=int(rng.integers(0, 8)))
+    model._opacity += float(rng.uniform(-2.0, 3.0))
+    bg = torch.tensor(rng.uniform(0, 1, 3), dtype=torch.float32)
+    st_o = make_settings(cam, bg, deg, scale_modifier=smod)
+    col, radii, aux = rasterize_ref(model.get_xyz, None, model.get_opacity, st_o, shs=model.get_features,
+                                    scales=model.get_scaling, rotations=model.get_rotation, want_aux=True, want_margin=True)
+    st = product_settings(cam, bg, deg, gpu_device, scale_modifier=smod)
+    out = forward_with_state(gpu_device, st, model.get_xyz, model.get_opacity, shs=model.get_features,
+                             scales=model.get_scaling, rotations=model.get_rotation, binning_mode=mode)
+    assert torch.equal(out["radii"], radii)
+    if mode != 2:      # the culled mode drops dead instances: its lists are checked in test_gpu_culled_binning.py
+        assert np.array_equal(out["keys"], aux["keys"]) and np.array_equal(out["point_list"], aux["point_list"])
+        assert np.array_equal(out["ranges"], aux["ranges"])
+    robust = aux["margin"] > 1e-4
+    err = ((out["color"] - col).abs() / col.abs().clamp(min=1.0)).max(dim=0).values
+    assert robust.any() and float(err[robust].max()) <= 1e-5
+    assert float(err.max()) <= 3.0 / 255.0
+    # gradients of an L1 loss against the float64 oracle
+    got, _ = _grads_product(gpu_device, model, cam, bg, target, deg)
+    # _grads_product uses scale_modifier 1: compare with an oracle at the same setting
+    ref, aux64 = _grads_oracle(model, cam, bg, target, deg)
+    # an independent float32 implementation (the oracle in float32) bounds what float32 arithmetic can deliver on this
+    # scene: random clouds contain Gaussians whose projection is ill-conditioned enough to miss 1e-5 in ANY float32 code
+    ref32, _ = _grads_oracle(model, cam, bg, target, deg, dtype=torch.float32)
+    n_fragile = int((aux64["margin"] <= 1e-4).sum())
+    for k, r in ref.items():
+        if r.numel() == 0:
+            continue
+        m = max(float(r.abs().max()), 1e-30)
+        e = float((got[k].double() - r).abs().max()) / m
+        e32 = float((ref32[k].double() - r).abs().max()) / m
+        tol = max(1e-5, 2.0 * e32) if n_fragile == 0 else 2e-3
+        assert e <= tol, (k, e, e32, n_fragile, dict(W=W, H=H, deg=deg, P=P, scale=scale))
