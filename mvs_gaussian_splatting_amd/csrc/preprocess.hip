@@ -678,11 +678,16 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(GsrParams p, 
           }
         }
       };
+      // d rgb / d dir: components that are identically zero are skipped (0 * c cannot be folded under IEEE rules and
+      // this file is built with -ffp-contract=off: the sums below may contract, they feed no integer decision)
       auto dirg = [&](int k, float bx, float by, float bz) {
+#pragma clang fp contract(fast)
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
           const float c = (M == 16) ? sreg[3 * k + ch] : s[3 * k + ch];
-          dRx[ch] += bx * c; dRy[ch] += by * c; dRz[ch] += bz * c;
+          if (!(__builtin_constant_p(bx) && bx == 0.0f)) dRx[ch] += bx * c;
+          if (!(__builtin_constant_p(by) && by == 0.0f)) dRy[ch] += by * c;
+          if (!(__builtin_constant_p(bz) && bz == 0.0f)) dRz[ch] += bz * c;
         }
       };
       emit(0, SH_C0);
