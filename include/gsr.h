@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 7
+#define GSR_ABI_VERSION 8
 
 enum {
   GSR_OK = 0,
@@ -75,6 +75,9 @@ typedef struct GsrParams {
                                   the scan kernel stores (num_rendered, num_visible) there and gsr_forward_preprocess
                                   waits on an event behind that kernel only, so the depth sort it has already
                                   enqueued keeps the GPU busy while the host sizes and launches stage 2 */
+  int32_t forward_only;        /* 1: no gsr_backward will follow (inference): the compositing kernel does not track the
+                                  last contributor and the per-pixel / per-Gaussian state the backward reads (final
+                                  transmittance, contributor counts, gradient-row slots) is not written.  Same image. */
 } GsrParams;
 
 enum {

@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class GsrParams(C.Structure):
@@ -26,7 +26,7 @@ class GsrParams(C.Structure):
         ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
         ("campos", C.c_void_p), ("bg", C.c_void_p), ("profile", C.c_void_p),
         ("shs_rest", C.c_void_p), ("act_flags", C.c_int32), ("binning_mode", C.c_int32),
-        ("counts_pinned", C.c_void_p),
+        ("counts_pinned", C.c_void_p), ("forward_only", C.c_int32),
     ]
 
 

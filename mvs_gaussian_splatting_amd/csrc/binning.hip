@@ -115,7 +115,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void compact_visible_kernel(int P, const
     didx[o] = (uint32_t)idx;
   }
   // slot range of this Gaussian's per-instance gradient rows: index-major (any bijection works), coalesced write
-  if (idx < P) slot_base[idx] = tbase + tinc - tiles;
+  if (slot_base && idx < P) slot_base[idx] = tbase + tinc - tiles;     // NULL: forward only
 }
 
 __global__ __launch_bounds__(PRE_BLOCK) void gather_tiles_kernel(uint32_t V, const uint32_t* __restrict__ didx,

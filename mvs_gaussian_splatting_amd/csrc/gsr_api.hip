@@ -179,7 +179,8 @@ int gsr_forward_preprocess(const GsrParams* p, void* geom_ws, int32_t* radii, vo
     // GPU sorts while the host round-trips (compaction + 32-bit depth sort of the visible Gaussians, device-side V)
     StageTimer t(p, GSR_STAGE_SORT, s);
     launch_compact_visible(p->P, at<BinInfo>(geom_ws, L.bin), at<uint32_t>(geom_ws, L.block_vis_offs),
-                           at<uint32_t>(geom_ws, L.block_offs), at<uint32_t>(geom_ws, L.slot_base),
+                           at<uint32_t>(geom_ws, L.block_offs),
+                           p->forward_only ? nullptr : at<uint32_t>(geom_ws, L.slot_base),
                            at<uint32_t>(geom_ws, L.dkey_a), at<uint32_t>(geom_ws, L.didx_a), s);
     launch_sort_pairs_u32(at<uint32_t>(geom_ws, L.dkey_a), at<uint32_t>(geom_ws, L.didx_a),
                           at<uint32_t>(geom_ws, L.dkey_b), at<uint32_t>(geom_ws, L.didx_b), (uint32_t)p->P, 32,
@@ -280,9 +281,10 @@ int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t b
   launch_build_tile_order(I.tiles, ranges, at<uint32_t>(img_ws, I.tile_order), s);
   {
     StageTimer t(p, GSR_STAGE_RENDER_FWD, s);
-    launch_render_fwd(p->width, p->height, ranges, point_list, rec, p->bg, out_color, at<float>(img_ws, I.final_T),
-                      at<uint32_t>(img_ws, I.n_contrib), at<uint32_t>(img_ws, I.tile_max),
-                      at<uint32_t>(img_ws, I.tile_order), s);
+    const bool track = !p->forward_only;
+    launch_render_fwd(p->width, p->height, ranges, point_list, rec, p->bg, out_color,
+                      track ? at<float>(img_ws, I.final_T) : nullptr, track ? at<uint32_t>(img_ws, I.n_contrib) : nullptr,
+                      track ? at<uint32_t>(img_ws, I.tile_max) : nullptr, at<uint32_t>(img_ws, I.tile_order), s);
   }
   return check(p, s, "render_fwd");
 }
@@ -290,6 +292,7 @@ int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t b
 int gsr_backward(const GsrParams* p, const int32_t* radii, const void* geom_ws, const void* bin_ws, const void* img_ws,
                  uint32_t R, uint32_t V, const float* dL_dout_color, void* bwd_ws, size_t bwd_ws_bytes,
                  const GsrGrads* grads, void* stream) {
+  if (p && p->forward_only) return fail(GSR_E_BADARG, "the forward ran with forward_only = 1: no state for a backward");
   if (int rc = validate(p)) return rc;
   if (!grads) return fail(GSR_E_BADARG, "grads is NULL");
   if (p->P == 0) return 0;

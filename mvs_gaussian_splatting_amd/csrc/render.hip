@@ -88,7 +88,7 @@ __device__ inline void make_lds(const Staged& st, LdsRec& o) {
 // Per-lane pixel state: T > 0 while the pixel is live.  A pixel that saturates keeps its final
 // transmittance with the sign flipped (T < 0; outside the image: T = 0), so every later
 // test_T = T*(1-alpha) <= 0 < 1e-4 keeps it out of the blend without a separate flag.
-template <bool STATS>
+template <bool STATS, bool TRACK>
 __device__ __forceinline__ void render_fwd_tile(const int tile, float4* sA, float4* sB, float* sC, int W, int H,
                                                 int grid_x, const uint2* __restrict__ ranges,
                                                 const uint32_t* __restrict__ point_list,
@@ -184,7 +184,7 @@ __device__ __forceinline__ void render_fwd_tile(const int tile, float4* sA, floa
             Cr[k] = fmaf(b.z, w, Cr[k]);
             Cg[k] = fmaf(b.w, w, Cg[k]);
             Cb[k] = fmaf(cb, w, Cb[k]);
-            last[k] = pos1;
+            if (TRACK) last[k] = pos1;
           }
           T[k] = go ? test_T : parked;
         }
@@ -204,14 +204,18 @@ __device__ __forceinline__ void render_fwd_tile(const int tile, float4* sA, floa
       out_color[pix] = Cr[k] + Tf * bg0;
       out_color[HW + pix] = Cg[k] + Tf * bg1;
       out_color[2 * HW + pix] = Cb[k] + Tf * bg2;
-      final_T[pix] = Tf;
-      n_contrib[pix] = last[k];
-      mx = max(mx, last[k]);
+      if (TRACK) {
+        final_T[pix] = Tf;
+        n_contrib[pix] = last[k];
+        mx = max(mx, last[k]);
+      }
     }
   }
+  if (TRACK) {
 #pragma unroll
-  for (int d = WAVE / 2; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, WAVE));
-  if (lane == 0) tile_max[tile] = mx;
+    for (int d = WAVE / 2; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, WAVE));
+    if (lane == 0) tile_max[tile] = mx;
+  }
   if (STATS && lane == 0) {
     atomicAdd(&stats[0], (unsigned long long)(end - start));
     atomicAdd(&stats[1], (unsigned long long)st_staged);
@@ -224,7 +228,8 @@ __device__ __forceinline__ void render_fwd_tile(const int tile, float4* sA, floa
 
 // One wave per tile; blockIdx walks the tiles longest-list-first (tile_order), so the hardware
 // dispatcher hands the short tiles to the slots that free up last.
-template <bool STATS>
+// TRACK = false (GsrParams.forward_only): nothing the backward needs is tracked or written
+template <bool STATS, bool TRACK>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) void render_fwd_kernel(int W, int H, int grid_x, int num_tiles,
                                                           const uint32_t* __restrict__ tile_order,
                                                           const uint2* __restrict__ ranges,
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) void render_fwd_kernel(int 
   const int slot = blockIdx.x * WAVES_PER_BLOCK + wid;
   if (slot >= num_tiles) return;
   const int tile = __builtin_amdgcn_readfirstlane((int)tile_order[slot]);
-  render_fwd_tile<STATS>(tile, sA[wid], sB[wid], sC[wid], W, H, grid_x, ranges, point_list, rec, bg, out_color, final_T, n_contrib,
+  render_fwd_tile<STATS, TRACK>(tile, sA[wid], sB[wid], sC[wid], W, H, grid_x, ranges, point_list, rec, bg, out_color, final_T, n_contrib,
                          tile_max, stats);
 }
 
@@ -464,10 +469,13 @@ void launch_render_fwd(int W, int H, const uint2* ranges, const uint32_t* point_
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   const int nblk = (gx * gy + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
   if (stats)
-    hipLaunchKernelGGL(render_fwd_kernel<true>, dim3(nblk), dim3(WAVES_PER_BLOCK * WAVE), 0, s, W, H, gx, gx * gy, tile_order, ranges,
+    hipLaunchKernelGGL((render_fwd_kernel<true, true>), dim3(nblk), dim3(WAVES_PER_BLOCK * WAVE), 0, s, W, H, gx, gx * gy, tile_order, ranges,
                        point_list, rec, bg, out_color, final_T, n_contrib, tile_max, stats);
-  else
-    hipLaunchKernelGGL(render_fwd_kernel<false>, dim3(nblk), dim3(WAVES_PER_BLOCK * WAVE), 0, s, W, H, gx, gx * gy, tile_order, ranges,
+  else if (final_T && n_contrib && tile_max)
+    hipLaunchKernelGGL((render_fwd_kernel<false, true>), dim3(nblk), dim3(WAVES_PER_BLOCK * WAVE), 0, s, W, H, gx, gx * gy, tile_order, ranges,
+                       point_list, rec, bg, out_color, final_T, n_contrib, tile_max, stats);
+  else      // forward only: no per-pixel state for a backward
+    hipLaunchKernelGGL((render_fwd_kernel<false, false>), dim3(nblk), dim3(WAVES_PER_BLOCK * WAVE), 0, s, W, H, gx, gx * gy, tile_order, ranges,
                        point_list, rec, bg, out_color, final_T, n_contrib, tile_max, stats);
 }
 void launch_render_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,

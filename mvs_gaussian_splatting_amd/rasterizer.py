@@ -86,7 +86,7 @@ def _stream(dev: torch.device) -> int:
 
 
 def _make_params(dev, settings: GaussianRasterizationSettings, means3D, sh, colors_precomp, opacities, scales,
-                 rotations, cov3Ds_precomp, sh_rest=None, act_flags: int = 0):
+                 rotations, cov3Ds_precomp, sh_rest=None, act_flags: int = 0, forward_only: bool = False):
     """Returns (GsrParams, keepalive list)."""
     bg = _f32c(settings.bg, "bg", dev)
     view = _f32c(settings.viewmatrix, "viewmatrix", dev)
@@ -113,13 +113,14 @@ def _make_params(dev, settings: GaussianRasterizationSettings, means3D, sh, colo
     p.act_flags = int(act_flags)
     p.binning_mode = _binning_mode()
     p.counts_pinned = _counts_pinned().data_ptr()
+    p.forward_only = int(bool(forward_only))
     return p, [bg, view, proj, campos]
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings: GaussianRasterizationSettings):
+                raster_settings: GaussianRasterizationSettings, forward_only: bool = False):
         lib = _lib.load()
         dev = _require_gpu(means3D)
         P = int(means3D.shape[0])
@@ -136,7 +137,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         with torch.cuda.device(dev):
             params, keep = _make_params(dev, raster_settings, means3D, sh, colors_precomp, opacities, scales,
-                                        rotations, cov3Ds_precomp)
+                                        rotations, cov3Ds_precomp, forward_only=forward_only)
             stream = _stream(dev)
             geom = torch.empty(lib.gsr_geom_bytes(P), dtype=torch.uint8, device=dev)
             img = torch.empty(lib.gsr_image_bytes(W, H), dtype=torch.uint8, device=dev)
@@ -209,7 +210,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise
         del keep
-        return g_means3D, g_means2D, g_sh, g_col, g_opac, g_scales, g_rot, g_cov, None
+        return g_means3D, g_means2D, g_sh, g_col, g_opac, g_scales, g_rot, g_cov, None, None
 
 
 class _RasterizeGaussiansFused(torch.autograd.Function):
@@ -220,7 +221,7 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations,
-                raster_settings: GaussianRasterizationSettings):
+                raster_settings: GaussianRasterizationSettings, forward_only: bool = False):
         lib = _lib.load()
         dev = _require_gpu(means3D)
         P = int(means3D.shape[0])
@@ -237,7 +238,7 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
         flags = _lib.ACT_SCALE_EXP | _lib.ACT_ROT_NORMALIZE | _lib.ACT_OPACITY_SIGMOID
         with torch.cuda.device(dev):
             params, keep = _make_params(dev, raster_settings, means3D, f_dc, empty, raw_opacity, raw_scales,
-                                        raw_rotations, empty, sh_rest=f_rest, act_flags=flags)
+                                        raw_rotations, empty, sh_rest=f_rest, act_flags=flags, forward_only=forward_only)
             stream = _stream(dev)
             geom = torch.empty(lib.gsr_geom_bytes(P), dtype=torch.uint8, device=dev)
             img = torch.empty(lib.gsr_image_bytes(W, H), dtype=torch.uint8, device=dev)
@@ -290,18 +291,25 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
                                         img.data_ptr(), R, ctx.num_visible, grad_out_color.data_ptr(), bwd_ws.data_ptr(), nbytes,
                                         C.byref(grads), stream), "gsr_backward")
         del keep
-        return g_means3D, g_means2D, g_dc, g_rest, g_opac, g_scales, g_rot, None
+        return g_means3D, g_means2D, g_dc, g_rest, g_opac, g_scales, g_rot, None, None
+
+
+def _forward_only(*tensors) -> bool:
+    """True when no backward can follow (inference): the library then skips everything only a backward reads."""
+    return not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors))
 
 
 def rasterize_gaussians_fused(means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations, raster_settings):
+    fo = _forward_only(means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations)
     return _RasterizeGaussiansFused.apply(means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations,
-                                          raster_settings)
+                                          raster_settings, fo)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
+    fo = _forward_only(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                                     cov3Ds_precomp, raster_settings, fo)
 
 
 class GaussianRasterizer(nn.Module):

@@ -728,3 +728,36 @@ def test_render_host_modes_and_leaf_reuse(gpu_device):
     assert float(p1["viewspace_points"].detach().abs().max()) == 0.0   # the shared zeros were never written
     # visibility filter / radii contract of the result dict
     assert torch.equal(p1["visibility_filter"], p1["radii"] > 0) and p1["selected_pts_mask"] is None
+
+
+def test_forward_only_variant_gives_the_same_image(gpu_device):
+    """GsrParams.forward_only (set by the operator under no_grad / when nothing requires grad): the compositing
+    variant that tracks nothing for a backward renders the same image bit for bit; a backward on it is refused."""
+    import ctypes as C
+    from mvs_gaussian_splatting_amd import render, _lib
+    from mvs_gaussian_splatting_amd.synthetic import PipelineParams
+    from test_gpu_parity import _stress_model
+    from mvs_gaussian_splatting_amd.synthetic import orbit_camera
+    dev = gpu_device
+    scenes = [small_scene(P=4000, sh_degree=3, width=200, height=120)[:3],
+              (_stress_model(), orbit_camera(1, 8, 208, 136, 120.0, 120.0), torch.tensor([0.2, 0.4, 0.1]))]
+    for model, cam, bg in scenes:
+        model.to(dev); cam.to(dev)
+        bg = bg.to(dev)
+        for fused in (True, False):
+            pipe = PipelineParams()
+            pipe.fuse_activations = fused
+            for p in model.parameters():
+                p.requires_grad_(True)
+            b = render(cam, model, pipe, bg)                 # a backward may follow: tracking variant
+            assert b["render"].grad_fn is not None
+            with torch.no_grad():
+                c = render(cam, model, pipe, bg)             # forward only
+            assert c["render"].grad_fn is None
+            assert torch.equal(b["render"].detach(), c["render"]) and torch.equal(b["radii"], c["radii"])
+    # the C ABI refuses a backward after a forward-only forward
+    p = _lib.GsrParams()
+    p.forward_only = 1
+    g = _lib.GsrGrads()
+    rc = _lib.load().gsr_backward(C.byref(p), None, None, None, None, 0, 0, None, None, 0, C.byref(g), None)
+    assert rc != 0 and b"forward_only" in _lib.load().gsr_last_error()
