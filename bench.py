@@ -106,6 +106,11 @@ def main():
                     help="feed the operator through the reference getters (cat/exp/normalize/sigmoid in torch)")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
+    # stdout carries exactly one line, the JSON result: native libraries (the RCCL / gloo banners) write to fd 1 too,
+    # so fd 1 is pointed at stderr for the run and the result goes to a duplicate of the original stdout
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch.distributed as dist
     from mvs_gaussian_splatting_amd import render, l1_loss, add_densification_stats, _lib
@@ -124,12 +129,34 @@ def main():
     dev = torch.device("cuda", 0 if share else local_rank)
     torch.cuda.set_device(dev)
     backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
+    backend_note = backend
+    cpu_collectives = backend != "nccl"      # gloo: the 16-byte collectives go through host tensors
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
+            # one group, two backends: RCCL for device tensors, gloo for host tensors.  RCCL communicators are created at
+            # the first collective: probe now, and if RCCL cannot come up on this node finish the measurement over the
+            # gloo half (the path's only collective is the 16-byte loss all-reduce) rather than not at all.
+            dist.init_process_group(backend="cpu:gloo,cuda:nccl")
+            try:
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize(dev)
+            except Exception as ex:  # noqa: BLE001
+                print(f"[bench] rank {rank}: nccl unavailable ({str(ex)[:200]!r}); using gloo for the loss all-reduce",
+                      file=sys.stderr, flush=True)
+                cpu_collectives = True
+                backend_note = "gloo (nccl failed to initialise)"
         else:
             dist.init_process_group(backend=backend)
+
+    def all_reduce(t, op):
+        if cpu_collectives:
+            h = t.detach().cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
 
     cfg = CONFIGS[args.config]
     P = args.gaussians or cfg.P
@@ -146,11 +173,12 @@ def main():
     M = (cfg.sh_degree + 1) ** 2
 
     def barrier():
+        torch.cuda.synchronize(dev)
         if world > 1:
-            if backend == "nccl":
-                dist.barrier(device_ids=[dev.index])
+            if cpu_collectives:
+                dist.all_reduce(torch.zeros(1))
             else:
-                dist.barrier()
+                dist.barrier(device_ids=[dev.index])
         torch.cuda.synchronize(dev)
 
     def fwd_step():
@@ -168,7 +196,7 @@ def main():
         add_densification_stats(model, pkg["viewspace_points"], pkg["radii"])
         if world > 1:     # the path's only collective: [loss_sum, l1_sum, n_views, pad]
             loss_vec[0] = loss.detach(); loss_vec[1] = loss.detach(); loss_vec[2] = 1.0
-            dist.all_reduce(loss_vec, op=dist.ReduceOp.SUM)
+            all_reduce(loss_vec, dist.ReduceOp.SUM)
         return pkg, loss
 
     for _ in range(args.warmup):
@@ -191,7 +219,7 @@ def main():
         dt = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            all_reduce(t, dist.ReduceOp.MAX)
             dt = float(t.item())
         per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(k))
         return dt, per_step
@@ -282,6 +310,7 @@ def main():
                        "gaussians": P, "visible": visible, "instances_R": R, "views_per_step": world,
                        "inputs": ("raw parameters (split SH, exp/normalize/sigmoid inside the kernels)"
                                   if pipe.fuse_activations else "reference getters (torch cat/exp/normalize/sigmoid)"),
+                       "collective_backend": backend_note if world > 1 else None,
                        "valid": args.gaussians is None},
             "roofline": roof,
             "roofline_by_kernel": table,
@@ -293,7 +322,7 @@ def main():
             except Exception as ex:  # noqa: BLE001
                 line["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": os.cpu_count(), "kind": "port",
                                         "sample": f"failed: {ex!r}"}
-        print(json.dumps(line), flush=True)
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
         barrier()
         dist.destroy_process_group()
