@@ -289,9 +289,21 @@ def main():
                 traffic = json.load(open(tfile)).get(args.config, {}).get(dominant, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        valu = None
+        try:
+            n_valu = json.load(open(tfile)).get(args.config, {}).get(dominant, {}).get("valu_insts_per_launch")
+            if n_valu:
+                # a wave64 fp32 VALU instruction occupies a SIMD for 4 cycles: 1024 SIMDs x 2.4 GHz / 4 per second
+                floor_ms = n_valu * 4.0 / (1024 * 2.4e9) * 1e3
+                valu = {"insts_per_launch": n_valu, "issue_floor_ms": round(floor_ms, 4),
+                        "floor_over_measured": round(floor_ms / table[dominant]["avg_ms"], 3),
+                        "source": "SQ_INSTS_VALU from a separate rocprofv3 --pmc pass of this command (profiles/)"}
+        except Exception:  # noqa: BLE001
+            valu = None
         roof = {"kernel": dominant, "bound": "hbm", "achieved": table[dominant]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": table[dominant]["frac_of_hbm_peak"], "traffic": traffic,
-                "avg_launch_ms": table[dominant]["avg_ms"], "algorithmic_bytes_per_launch": alg[dominant]}
+                "avg_launch_ms": table[dominant]["avg_ms"], "algorithmic_bytes_per_launch": alg[dominant],
+                "valu_issue": valu}
         fwd_ms = t_fwd / K * 1e3
         train_ms = t_train / K * 1e3
         line = {

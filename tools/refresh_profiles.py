@@ -51,4 +51,22 @@ with open(os.path.join(dst, "pmc_SQ_render_summary.txt"), "w") as f:
 here = os.path.dirname(os.path.abspath(__file__))
 subprocess.run([sys.executable, os.path.join(here, "traffic_from_pmc.py"), os.path.join(src, "fetch"), os.path.join(src, "write"), "C4"],
                check=True, stdout=subprocess.DEVNULL)
+# VALU instruction counts next to the HBM bytes: bench.py reports the issue floor of the dominant kernel from them
+import json
+tpath = os.path.join(os.path.dirname(os.path.abspath(dst.rstrip("/"))), "traffic.json")
+tj = json.load(open(tpath))
+names = {"preprocess_fwd_kernel": "preprocess_fwd", "render_fwd_kernel": "render_fwd", "render_bwd_kernel": "render_bwd",
+         "preprocess_bwd_kernel": "preprocess_bwd"}
+for k, m in agg.items():
+    base = k.split("<")[0].split("::")[-1]
+    if base in names and "SQ_INSTS_VALU" in m:
+        e = tj["C4"].setdefault(names[base], {})
+        vals = e.setdefault("_valu", [])
+        vals.append(sum(m["SQ_INSTS_VALU"]) / len(m["SQ_INSTS_VALU"]))
+for e in tj["C4"].values():
+    if "_valu" in e:
+        v = e.pop("_valu")
+        e["valu_insts_per_launch"] = int(max(v))      # the tracking variant when a kernel has two
+        e["valu_method"] = "rocprofv3 --pmc SQ_INSTS_VALU, per-launch mean (wave-level instructions)"
+json.dump(tj, open(tpath, "w"), indent=1)
 print(open(os.path.join(dst, "pmc_SQ_render_summary.txt")).read())
