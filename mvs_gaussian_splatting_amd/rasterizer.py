@@ -150,7 +150,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                            "gsr_forward_preprocess")
                 R, V = int(num_rendered.value), int(num_visible.value)
                 nbytes = lib.gsr_binning_bytes(R, V, W, H, params.binning_mode)
-                binning = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                binning = torch.empty(_round_ws(nbytes), dtype=torch.uint8, device=dev)
                 _lib.check(lib.gsr_forward_render(C.byref(params), geom.data_ptr(), binning.data_ptr(), nbytes,
                                                   img.data_ptr(), R, V, color.data_ptr(), stream), "gsr_forward_render")
             except _lib.GsrError:
@@ -198,7 +198,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             grads = _lib.GsrGrads(_ptr(g_means3D), _ptr(g_means2D), _ptr(g_sh), _ptr(g_col), _ptr(g_opac),
                                   _ptr(g_scales), _ptr(g_rot), _ptr(g_cov), None)
             nbytes = lib.gsr_backward_bytes(P, R)
-            bwd_ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            bwd_ws = torch.empty(_round_ws(nbytes), dtype=torch.uint8, device=dev)
             try:
                 _lib.check(lib.gsr_backward(C.byref(params), _ptr(radii), geom.data_ptr(), binning.data_ptr(),
                                             img.data_ptr(), R, ctx.num_visible, grad_out_color.data_ptr(), bwd_ws.data_ptr(), nbytes,
@@ -249,7 +249,7 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
                                                   C.byref(num_rendered), C.byref(num_visible)), "gsr_forward_preprocess")
             R, V = int(num_rendered.value), int(num_visible.value)
             nbytes = lib.gsr_binning_bytes(R, V, W, H, params.binning_mode)
-            binning = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            binning = torch.empty(_round_ws(nbytes), dtype=torch.uint8, device=dev)
             _lib.check(lib.gsr_forward_render(C.byref(params), geom.data_ptr(), binning.data_ptr(), nbytes,
                                               img.data_ptr(), R, V, color.data_ptr(), stream), "gsr_forward_render")
         ctx.raster_settings = raster_settings
@@ -286,12 +286,19 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
             grads = _lib.GsrGrads(_ptr(g_means3D), _ptr(g_means2D), _ptr(g_dc), None, _ptr(g_opac), _ptr(g_scales),
                                   _ptr(g_rot), None, _ptr(g_rest))
             nbytes = lib.gsr_backward_bytes(P, R)
-            bwd_ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            bwd_ws = torch.empty(_round_ws(nbytes), dtype=torch.uint8, device=dev)
             _lib.check(lib.gsr_backward(C.byref(params), _ptr(radii), geom.data_ptr(), binning.data_ptr(),
                                         img.data_ptr(), R, ctx.num_visible, grad_out_color.data_ptr(), bwd_ws.data_ptr(), nbytes,
                                         C.byref(grads), stream), "gsr_backward")
         del keep
         return g_means3D, g_means2D, g_dc, g_rest, g_opac, g_scales, g_rot, None, None
+
+
+def _round_ws(nbytes: int) -> int:
+    """Workspace sizes that depend on the per-view instance count are rounded up to 32 MiB steps, so that the caching
+    allocator reuses one block from frame to frame instead of growing a new size class per view."""
+    step = 1 << 25
+    return max(step, (int(nbytes) + step - 1) // step * step)
 
 
 def _forward_only(*tensors) -> bool:
