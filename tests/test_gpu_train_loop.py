@@ -35,3 +35,26 @@ def test_training_loop_converges_and_state_stays_consistent(tmp_path):
     back = load_ply(path)
     for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
         assert torch.equal(back[k].cpu(), getattr(model, k).detach().cpu()), k
+
+
+def test_offline_render_of_a_saved_ply_matches_the_live_model(tmp_path):
+    """render.py's path: save_ply -> load_ply -> render under no_grad gives the images of the live model bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from train_synthetic import make_problem
+    from render_ply import render_set
+    from mvs_gaussian_splatting_amd import render
+    from mvs_gaussian_splatting_amd.ply_io import save_ply
+    from mvs_gaussian_splatting_amd.synthetic import orbit_camera
+    dev = torch.device("cuda:0")
+    _, _, bg, pipe, model = make_problem(dev, P=3000)
+    path = str(tmp_path / "point_cloud.ply")
+    save_ply(model, path)
+    _, images = render_set(path, str(tmp_path / "renders"), n_views=3, width=200, height=120)
+    for v, img in enumerate(images):
+        cam = orbit_camera(v, 3, 200, 120, 220.0, 220.0, centre=(0.0, 0.0, 4.0), device=dev)
+        with torch.no_grad():
+            live = render(cam, model, pipe, bg)["render"]
+        assert torch.equal(img, live)
+        data = open(tmp_path / "renders" / f"{v:05d}.ppm", "rb").read()
+        assert data.startswith(b"P6\n200 120\n255\n") and len(data) == 15 + 200 * 120 * 3
