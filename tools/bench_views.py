@@ -1,0 +1,43 @@
+"""Per-view cost of the C5 orbit (view v = 45 deg * v about the cloud centre): what each rank of the
+multi-GPU bench renders.  python tools/bench_views.py"""
+import time
+import torch
+from mvs_gaussian_splatting_amd import render, l1_loss
+from mvs_gaussian_splatting_amd.synthetic import CONFIGS, make_scene, PipelineParams
+
+dev = torch.device("cuda:0")
+cfg = CONFIGS["C4"]
+model, _, bg, _ = make_scene(cfg)
+model.to(dev)
+bg = bg.to(dev)
+for p in model.parameters():
+    p.requires_grad_(True)
+pipe = PipelineParams()
+for v in range(8):
+    _, cam, _, target = make_scene(cfg, P=1, view=v, n_views=8)
+    cam.to(dev); target = target.to(dev)
+
+    def fwd():
+        with torch.no_grad():
+            return render(cam, model, pipe, bg)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        pkg = render(cam, model, pipe, bg)
+        l1_loss(pkg["render"], target).backward()
+        return pkg
+
+    for _ in range(2):
+        fwd(); pkg = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        fwd()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"view {v}: visible {int((pkg['radii'] > 0).sum()):>8}  R {pkg['render'].grad_fn.num_rendered:>9}  fwd {(t1 - t0) * 100:.3f} ms  train {(t2 - t1) * 100:.3f} ms", flush=True)
