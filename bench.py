@@ -43,9 +43,22 @@ def algorithmic_bytes(P, M, R, W, H, passes):
     }
 
 
-def usable_cores():
-    """Host cores this process may really use: affinity mask, cgroup CPU quota, and a cap of 16 (a 1-GPU box's
-    share); os.cpu_count() on a big host oversubscribes the OpenMP pool by an order of magnitude."""
+def source_stamp():
+    """sha256[:16] over the kernel sources + ABI header: ties profiles/traffic.json (PMC passes taken at one state of
+    the kernels) to the library this run measures; .git does not travel to the GPU box, the sources do."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "mvs_gaussian_splatting_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "mvs_gaussian_splatting_amd", "csrc", "*.h")) +
+                   [os.path.join(ROOT, "include", "gsr.h")])
+    for f in files:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def host_cores():
+    """(cores this process may use by affinity mask and cgroup CPU quota, os.cpu_count() of the host)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         q, p = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -53,19 +66,30 @@ def usable_cores():
             n = min(n, max(1, int(float(q) / float(p))))
     except Exception:
         pass
-    return max(1, min(n, 16))
+    return max(1, n), os.cpu_count() or 1
 
 
-def cpu_baseline(cfg, seed, budget_tiles=1024):
-    """Pure-PyTorch CPU oracle timed on the host cores over a bounded sample of the same workload: full
-    preprocess + full binning, compositing forward (+ L1 + backward) on every k-th tile, extrapolated."""
+def usable_cores():
+    """Threads the CPU baseline runs on: the usable cores, capped at 16 (a 1-GPU box's share; os.cpu_count() on a big
+    host oversubscribes the OpenMP pool by an order of magnitude).  The uncapped numbers are reported beside it."""
+    return min(host_cores()[0], 16)
+
+
+def cpu_baseline(cfg, seed, budget_tiles=1024, bwd_tiles=96):
+    """Pure-PyTorch CPU oracle (float32) timed on the host cores over a bounded sample of the same workload:
+    forward = full preprocess + full binning + compositing of every k-th tile, extrapolated;
+    train step = the same under autograd + L1 + backward, on a smaller tile sample (the autograd graph of the
+    compositing holds every per-chunk intermediate), extrapolated the same way."""
     from oracle import RasterSettings, preprocess_ref, bin_ref, render_tiles_ref
     from mvs_gaussian_splatting_amd.synthetic import make_scene
-    torch.set_num_threads(usable_cores())
+    threads = usable_cores()
+    usable, host = host_cores()
+    torch.set_num_threads(threads)
     print(f"[bench] cpu_baseline: oracle on {torch.get_num_threads()} threads ...", file=sys.stderr, flush=True)
     model, cam, bg, target = make_scene(cfg, seed=seed)
     st = RasterSettings(cam.image_height, cam.image_width, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0,
                         cam.world_view_transform, cam.full_proj_transform, cfg.sh_degree, cam.camera_center)
+    W, H = cfg.width, cfg.height
     with torch.no_grad():
         t0 = time.perf_counter()
         pre = preprocess_ref(model.get_xyz, model.get_opacity, st, shs=model.get_features,
@@ -84,13 +108,37 @@ def cpu_baseline(cfg, seed, budget_tiles=1024):
         t4 = time.perf_counter()
     scale = n_tiles / len(tiles)
     fwd_s = (t1 - t0) + (t2 - t1) + (t4 - t3) * scale
-    W, H = cfg.width, cfg.height
+    print(f"[bench] cpu_baseline: forward sample {t4 - t3:.1f}s; train-step sample ...", file=sys.stderr, flush=True)
+    # ---- train step: forward under autograd + L1 + backward (fp32), compositing restricted to a tile sample
+    del pre
+    leaves = [p.detach().clone().requires_grad_(True) for p in
+              (model._xyz, model._features_dc, model._features_rest, model._scaling, model._rotation, model._opacity)]
+    stride_b = max(1, int(math.ceil(n_tiles / bwd_tiles)))
+    tiles_b = list(range(stride_b // 2, n_tiles, stride_b))
+    b0 = time.perf_counter()
+    pre = preprocess_ref(leaves[0], torch.sigmoid(leaves[5]), st, shs=torch.cat((leaves[1], leaves[2]), dim=1),
+                         scales=torch.exp(leaves[3]), rotations=torch.nn.functional.normalize(leaves[4]))
+    b1 = time.perf_counter()
+    col = render_tiles_ref(pre, plist, ranges, st, tiles=tiles_b)[0]
+    b2 = time.perf_counter()
+    loss = (col - target).abs().mean()
+    loss.backward()
+    b3 = time.perf_counter()
+    # the backward of the compositing scales with the tile sample, the backward of preprocess does not; both are inside
+    # (b3 - b2), so scaling all of it overstates the CPU time slightly -- the split is reported
+    scale_b = n_tiles / len(tiles_b)
+    step_s = (b1 - b0) + (t2 - t1) + (b2 - b1) * scale_b + (b3 - b2) * scale_b
     return {
         "value": W * H / fwd_s / 1e6, "unit": "Mpixels/s", "cores": torch.get_num_threads(), "kind": "port",
+        "host_cores_usable": usable, "host_cores_total": host,
         "sample": (f"pure-PyTorch fp32 oracle, forward: full preprocess ({t1 - t0:.1f}s) + full binning "
                    f"({t2 - t1:.1f}s) + compositing of {len(tiles)}/{n_tiles} tiles ({t4 - t3:.1f}s, x{scale:.0f} "
-                   f"extrapolated) -> {fwd_s:.1f}s per 1080p frame"),
+                   f"extrapolated) -> {fwd_s:.1f}s per {W}x{H} frame; train step: preprocess under autograd "
+                   f"({b1 - b0:.1f}s) + binning + compositing of {len(tiles_b)}/{n_tiles} tiles ({b2 - b1:.1f}s) + L1 "
+                   f"+ backward ({b3 - b2:.1f}s), tile-dependent parts x{scale_b:.0f} -> {step_s:.0f}s per step"),
         "fwd_seconds_extrapolated": fwd_s,
+        "train_step_seconds_extrapolated": step_s,
+        "train_step_ms": step_s * 1e3,
     }
 
 
@@ -131,22 +179,36 @@ def main():
     backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
     backend_note = backend
     cpu_collectives = backend != "nccl"      # gloo: the 16-byte collectives go through host tensors
+    rccl_ranks = None                        # communicator size proven by an all-reduce of ones over RCCL
+    rccl_failed = False
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             # one group, two backends: RCCL for device tensors, gloo for host tensors.  RCCL communicators are created at
-            # the first collective: probe now, and if RCCL cannot come up on this node finish the measurement over the
-            # gloo half (the path's only collective is the 16-byte loss all-reduce) rather than not at all.
+            # the first collective: probe now.  The outcome is AGREED over the gloo half (MIN of the per-rank flags), so
+            # that every rank issues the same collectives afterwards; a run that had to fall back to gloo still reports
+            # its timings as diagnostics but is marked invalid (it did not measure the RCCL-over-xGMI all-reduce).
             dist.init_process_group(backend="cpu:gloo,cuda:nccl")
+            ok, why = 1, ""
             try:
                 probe = torch.ones(1, device=dev)
                 dist.all_reduce(probe)
                 torch.cuda.synchronize(dev)
+                ok = int(round(float(probe.item()))) == world
+                if not ok:
+                    why = f"all-reduce of ones returned {float(probe.item())}, expected {world}"
             except Exception as ex:  # noqa: BLE001
-                print(f"[bench] rank {rank}: nccl unavailable ({str(ex)[:200]!r}); using gloo for the loss all-reduce",
-                      file=sys.stderr, flush=True)
+                ok, why = 0, str(ex)[:300]
+            flag = torch.tensor([int(ok)], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # host tensor -> gloo
+            if int(flag.item()) == 1:
+                rccl_ranks = world
+            else:
+                rccl_failed = True
                 cpu_collectives = True
-                backend_note = "gloo (nccl failed to initialise)"
+                backend_note = "gloo (nccl failed to initialise on at least one rank)"
+                print(f"[bench] rank {rank}: RCCL unavailable on this or another rank ({why!r}); every rank switches to "
+                      "gloo for the 16-byte loss all-reduce and the line is marked invalid", file=sys.stderr, flush=True)
         else:
             dist.init_process_group(backend=backend)
 
@@ -251,6 +313,20 @@ def main():
         t_train, train_steps = timed(train_step, K)
         stages_train = prof.collect()
     prof.close()
+    # The literal drop-in (INTEGRATION.md option A: the reference's own render() feeding the operator through the
+    # getters of scene/gaussian_model.py:151-183 -- torch cat / exp / normalize / sigmoid and their autograd) next to
+    # the fused raw-parameter path the headline numbers use; a shorter timed region of the same protocol.
+    unfused = None
+    if pipe.fuse_activations and world == 1:
+        pipe.fuse_activations = False
+        k2 = max(3, K // 4)
+        for _ in range(2):
+            fwd_step(); train_step()
+        t_uf, _ = timed(fwd_step, k2)
+        t_ut, _ = timed(train_step, k2)
+        unfused = {"unfused_fwd_ms": round(t_uf / k2 * 1e3, 3), "unfused_train_ms": round(t_ut / k2 * 1e3, 3),
+                   "unfused_steps": k2}
+        pipe.fuse_activations = True
 
     # instances of this rank's view: read back from the stage the operator itself ran
     R = int(getattr(pkg["render"].grad_fn, "num_rendered", 0)) if pkg["render"].grad_fn is not None else 0
@@ -280,30 +356,50 @@ def main():
         fwd_names = ["preprocess_fwd", "scan_block_sums", "duplicate_with_keys", "radix_sort", "identify_tile_ranges",
                      "render_fwd"]
         dominant = max((n for n in table), key=lambda n: table[n]["avg_ms"] * (1 if n in fwd_names else 0))
-        traffic = None
+        # HBM bytes and instruction counts per launch of the dominant kernel come from SEPARATE rocprofv3 --pmc passes
+        # of this same command (tools/refresh_profiles.py -> profiles/traffic.json).  The file carries the stamp of the
+        # kernel sources it was measured on: on a mismatch the fields are nulled rather than quoted stale.
+        traffic, issue, pmc_note = None, None, "no PMC measurement on file for this config"
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
-            try:
-                # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, gfx950-corrected) of this
-                # same command, recorded by tools/traffic_from_pmc.py; null when no measurement is on file
-                traffic = json.load(open(tfile)).get(args.config, {}).get(dominant, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        valu = None
         try:
-            n_valu = json.load(open(tfile)).get(args.config, {}).get(dominant, {}).get("valu_insts_per_launch")
-            if n_valu:
-                # a wave64 fp32 VALU instruction occupies a SIMD for 4 cycles: 1024 SIMDs x 2.4 GHz / 4 per second
-                floor_ms = n_valu * 4.0 / (1024 * 2.4e9) * 1e3
-                valu = {"insts_per_launch": n_valu, "issue_floor_ms": round(floor_ms, 4),
-                        "floor_over_measured": round(floor_ms / table[dominant]["avg_ms"], 3),
-                        "source": "SQ_INSTS_VALU from a separate rocprofv3 --pmc pass of this command (profiles/)"}
-        except Exception:  # noqa: BLE001
-            valu = None
+            tj = json.load(open(tfile))
+            stamp = tj.get("_stamp", {}).get(args.config, {})
+            entry = tj.get(args.config, {}).get(dominant, {})
+            if not entry:
+                pass
+            elif stamp.get("source_sha16") != source_stamp() or stamp.get("abi") != _lib.load().gsr_abi_version():
+                pmc_note = (f"profiles/traffic.json was measured at kernel sources {stamp.get('source_sha16')} / ABI "
+                            f"{stamp.get('abi')}, this run is {source_stamp()} / ABI {_lib.load().gsr_abi_version()}: "
+                            "PMC-derived fields nulled")
+            else:
+                traffic = entry.get("hbm_bytes_per_launch")
+                pmc_note = f"rocprofv3 --pmc passes at kernel sources {stamp.get('source_sha16')} ({stamp.get('label', '')})"
+                sq = entry.get("sq", {})
+                if sq.get("SQ_INSTS_VALU"):
+                    t_s = table[dominant]["avg_ms"] * 1e-3
+                    clk = 2.4e9
+                    # measured issue rates (tools/ubench/valu_rate.hip, profiles/r02/valu_rate.txt): a wave64 VALU
+                    # instruction occupies its SIMD for >= 2 cycles (v_exp_f32 8, v_cmp / v_cndmask 4), a SALU
+                    # instruction is issued at most every 4 cycles per SIMD; 1024 SIMDs
+                    valu_u = sq["SQ_INSTS_VALU"] * 2.0 / (1024 * clk * t_s)
+                    salu_u = sq.get("SQ_INSTS_SALU", 0) * 4.0 / (1024 * clk * t_s)
+                    lds_u = sq.get("SQ_INSTS_LDS", 0) * 4.0 / (256 * clk * t_s)
+                    util = {"valu_issue (2 cycles per wave64 instruction)": round(valu_u, 3),
+                            "salu_issue (4 cycles per instruction per SIMD)": round(salu_u, 3),
+                            "lds (4 cycles per ds_read_b128 per CU)": round(lds_u, 3)}
+                    if sq.get("SQ_ACTIVE_INST_VALU") and sq.get("SQ_BUSY_CYCLES"):
+                        util["valu_pipe_busy (SQ_ACTIVE_INST_VALU x 4 / SIMD cycles)"] = round(
+                            sq["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024 * clk * t_s), 3)
+                    issue = {"insts_per_launch": {k: int(v) for k, v in sq.items()}, "utilisation": util,
+                             "limiter": max(util, key=util.get),
+                             "note": "utilisations are lower bounds of the unit's busy share at the 2.4 GHz peak clock "
+                                     "(the chip clocks lower under VALU load) and cannot exceed 1"}
+        except Exception as ex:  # noqa: BLE001
+            pmc_note = f"profiles/traffic.json unreadable: {ex!r}"
         roof = {"kernel": dominant, "bound": "hbm", "achieved": table[dominant]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": table[dominant]["frac_of_hbm_peak"], "traffic": traffic,
                 "avg_launch_ms": table[dominant]["avg_ms"], "algorithmic_bytes_per_launch": alg[dominant],
-                "valu_issue": valu}
+                "issue": issue, "pmc_source": pmc_note}
         fwd_ms = t_fwd / K * 1e3
         train_ms = t_train / K * 1e3
         line = {
@@ -323,11 +419,16 @@ def main():
                        "inputs": ("raw parameters (split SH, exp/normalize/sigmoid inside the kernels)"
                                   if pipe.fuse_activations else "reference getters (torch cat/exp/normalize/sigmoid)"),
                        "collective_backend": backend_note if world > 1 else None,
-                       "valid": args.gaussians is None},
+                       "rccl_ranks": rccl_ranks,
+                       # invalid: a reduced problem, or ranks on distinct devices whose RCCL communicator did not come
+                       # up (the gloo numbers are diagnostics, not the north-star collective)
+                       "valid": args.gaussians is None and not (rccl_failed and not share)},
             "roofline": roof,
             "roofline_by_kernel": table,
             "fwd_algorithmic_GB": round(sum(alg[n] for n in fwd_names) / 1e9, 3),
         }
+        if unfused:
+            line.update(unfused)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(cfg, args.seed)

@@ -15,7 +15,7 @@
  *     memory and keeps no global mutable state (forward and backward arrive on different OS
  *     threads: train.py:107 runs backward on an autograd engine thread);
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it; the only host
- *     synchronisation is the read-back of num_rendered in gsr_forward_bin_count();
+ *     synchronisation is the read-back of (num_rendered, num_visible) in gsr_forward_preprocess();
  *   - return value 0 = success, >0 = hipError_t, <0 = library error (GSR_E_*); the message is
  *     available per thread from gsr_last_error();
  *   - all float tensors are contiguous fp32; matrices are the row-vector-convention 4x4s the
@@ -31,14 +31,13 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 8
+#define GSR_ABI_VERSION 9
 
 enum {
   GSR_OK = 0,
   GSR_E_BADARG = -1,    /* null / inconsistent arguments (both-or-neither of shs/colors, scales+rotations/cov3D) */
   GSR_E_CAPACITY = -2,  /* binning workspace smaller than gsr_binning_bytes(num_rendered) */
-  GSR_E_ALIGN = -3,     /* a pointer violates the documented alignment */
-  GSR_E_PREFILTER = -4  /* prefiltered=1 but a Gaussian failed the near-plane cull (debug builds of the check) */
+  GSR_E_ALIGN = -3      /* a pointer violates the documented alignment */
 };
 
 /* One call's inputs.  Replaces the positional arguments of the reference-side
@@ -52,7 +51,8 @@ typedef struct GsrParams {
   int32_t width, height;  /* settings.image_width / image_height */
   float tan_fovx, tan_fovy;
   float scale_modifier;
-  int32_t prefiltered;
+  int32_t prefiltered;    /* accepted and ignored: the reference always passes False (gaussian_renderer/__init__.py:53);
+                             culled Gaussians are simply skipped whatever its value */
   int32_t debug;          /* 1: synchronise and check after every kernel */
   const float* means3D;        /* device [P,3] */
   const float* shs;            /* device [P,M,3] or NULL (16-byte aligned) */
@@ -188,9 +188,12 @@ const char* gsr_stage_name(int32_t stage);
 
 /* ---- caller-side steps of the train loop ---------------------------- */
 /* L1 loss (utils/loss_utils.py:17-18) forward + gradient in one pass:
- * loss_sum[0] += sum|x-gt| (caller zero-fills, divides by n), dL_dx = sign(x-gt) * scale. */
+ * loss_sum[0] = sum|x-gt| (written, not accumulated; the caller divides by n), dL_dx = sign(x-gt) * scale.
+ * `workspace`: device scratch of gsr_l1_loss_workspace_bytes() for the per-block partial sums, which are added in a
+ * fixed order (no atomics): the loss is bitwise reproducible from run to run. */
+size_t gsr_l1_loss_workspace_bytes(void);
 int gsr_l1_loss_fwd_bwd(const float* x, const float* gt, size_t n, float scale, float* loss_sum,
-                        float* dL_dx, void* stream);
+                        float* dL_dx, void* workspace, void* stream);
 /* The reference's training loss (train.py:99-101) in two kernels: (1-lambda)*L1 + lambda*(1 - SSIM) with SSIM as
  * utils/loss_utils.py:23-63 (11x11 Gaussian window, sigma 1.5, zero padding, mean over C*H*W).
  * dssim_mode GSR_DSSIM_ONE_MINUS_MEAN: sums[0] += sum|x-gt|, sums[1] += sum SSIM

@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class GsrParams(C.Structure):
@@ -66,8 +66,9 @@ SYMBOLS = {
                                          C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsr_debug_read_image": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
+    "gsr_l1_loss_workspace_bytes": (C.c_size_t, []),
     "gsr_l1_loss_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p,
-                                      C.c_void_p]),
+                                      C.c_void_p, C.c_void_p]),
     "gsr_debug_render_stats": (C.c_int, [C.POINTER(GsrParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                          C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsr_l1_dssim_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
@@ -147,11 +148,15 @@ class StageProfile:
         check(load().gsr_profile_create(C.byref(self._h)), "gsr_profile_create")
 
     def __enter__(self):
-        _active_profile.h = self._h
+        _active_profile.obj = self
         return self
 
     def __exit__(self, *exc):
-        _active_profile.h = None
+        _active_profile.obj = None
+
+    def handle(self):
+        """The native handle, or None once closed (a backward that outlives close() then runs untimed)."""
+        return self._h if self._h else None
 
     def collect(self):
         """-> {stage name: (total ms, intervals)}; blocks on the recorded events and clears them."""
@@ -173,5 +178,12 @@ class StageProfile:
             pass
 
 
+def active_profile():
+    """The StageProfile active on this thread (autograd contexts hold on to the object, not the raw handle, so
+    that the handle cannot be freed under a retained graph's backward)."""
+    return getattr(_active_profile, "obj", None)
+
+
 def active_profile_handle():
-    return getattr(_active_profile, "h", None)
+    obj = active_profile()
+    return obj.handle() if obj is not None else None

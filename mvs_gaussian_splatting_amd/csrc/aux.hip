@@ -7,10 +7,13 @@
 
 namespace gsr {
 
-// loss_sum += sum |x - gt| ; dL_dx = sign(x - gt) * scale.  Streaming, 16 B per lane.
+// partials[block] = sum over the block's elements of |x - gt| ; dL_dx = sign(x - gt) * scale.  Streaming, 16 B per lane.
+// No atomics: the block partials are summed in block order by l1_loss_finish_kernel, so the loss is bitwise
+// reproducible from run to run (like loss.hip's ordered sums and the atomic-free backward).
 constexpr int L1_THREADS = 1024;
+constexpr int L1_MAX_BLOCKS = 512;     // two 16-wave blocks per CU
 __global__ __launch_bounds__(L1_THREADS) void l1_loss_kernel(const float* __restrict__ x, const float* __restrict__ gt,
-                                                             size_t n, float scale, float* __restrict__ loss_sum,
+                                                             size_t n, float scale, float* __restrict__ partials,
                                                              float* __restrict__ dL_dx) {
   __shared__ float wsum[L1_THREADS / WAVE];
   const size_t n4 = n / 4;
@@ -36,8 +39,16 @@ __global__ __launch_bounds__(L1_THREADS) void l1_loss_kernel(const float* __rest
     float s = 0.0f;
 #pragma unroll
     for (int w = 0; w < L1_THREADS / WAVE; ++w) s += wsum[w];
-    atomicAdd(loss_sum, s);     // <= 512 blocks: atomics on one address serialise at ~12 ns each
+    partials[blockIdx.x] = s;
   }
+}
+// one wave: lane l sums partials l, l+64, ... in order, then a fixed butterfly
+__global__ __launch_bounds__(WAVE) void l1_loss_finish_kernel(const float* __restrict__ partials, int blocks,
+                                                              float* __restrict__ loss_sum) {
+  float acc = 0.0f;
+  for (int i = threadIdx.x; i < blocks; i += WAVE) acc += partials[i];
+  acc = wave_reduce_add_f32(acc);
+  if (threadIdx.x == 0) loss_sum[0] = acc;
 }
 
 __global__ __launch_bounds__(256) void densify_stats_kernel(int P, const float* __restrict__ dL_dmeans2D,
@@ -107,12 +118,14 @@ __global__ __launch_bounds__(PRE_BLOCK) void unpack_geom_kernel(int P, const Geo
 }
 
 
+size_t l1_loss_workspace_bytes() { return sizeof(float) * L1_MAX_BLOCKS; }
 void launch_l1_loss(const float* x, const float* gt, size_t n, float scale, float* loss_sum, float* dL_dx,
-                    hipStream_t s) {
+                    float* partials, hipStream_t s) {
   size_t blocks = (n / 4 + L1_THREADS - 1) / L1_THREADS;
-  if (blocks > 512) blocks = 512;     // two 16-wave blocks per CU
+  if (blocks > (size_t)L1_MAX_BLOCKS) blocks = L1_MAX_BLOCKS;
   if (blocks == 0) blocks = 1;
-  hipLaunchKernelGGL(l1_loss_kernel, dim3((unsigned)blocks), dim3(L1_THREADS), 0, s, x, gt, n, scale, loss_sum, dL_dx);
+  hipLaunchKernelGGL(l1_loss_kernel, dim3((unsigned)blocks), dim3(L1_THREADS), 0, s, x, gt, n, scale, partials, dL_dx);
+  hipLaunchKernelGGL(l1_loss_finish_kernel, dim3(1), dim3(WAVE), 0, s, partials, (int)blocks, loss_sum);
 }
 void launch_densify_stats(int P, const float* dL_dmeans2D, const int32_t* radii, float* accum, float* denom,
                           float* max_radii2D, hipStream_t s) {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -76,16 +77,28 @@ int validate(const GsrParams* p) {
 }
 
 // ---- opt-in stage timers: event pairs recorded on the caller's stream ----------------------------
+// Forward and backward of one frame arrive on different OS threads (autograd engine): every access takes `mu`.
 struct Profile {
   struct Span { int stage; hipEvent_t a, b; };
+  std::mutex mu;
   std::vector<Span> used;
   std::vector<hipEvent_t> pool;
   hipEvent_t get() {
+    std::lock_guard<std::mutex> lock(mu);
     if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
   }
+  void push(const Span& sp) {
+    std::lock_guard<std::mutex> lock(mu);
+    used.push_back(sp);
+  }
+};
+// an event that is destroyed on every exit path
+struct ScopedEvent {
+  hipEvent_t e = nullptr;
+  ~ScopedEvent() { if (e) (void)hipEventDestroy(e); }
 };
 struct StageTimer {
   Profile* pr; hipStream_t s; Profile::Span sp;
@@ -97,7 +110,7 @@ struct StageTimer {
   ~StageTimer() {
     if (!pr) return;
     if (sp.b) (void)hipEventRecord(sp.b, s);
-    pr->used.push_back(sp);
+    pr->push(sp);
   }
 };
 
@@ -169,10 +182,10 @@ int gsr_forward_preprocess(const GsrParams* p, void* geom_ws, int32_t* radii, vo
                            L.nblocks, s, p->counts_pinned);
   }
   if (int rc = check(p, s, "scan_block_sums")) return rc;
-  hipEvent_t counted = nullptr;
+  ScopedEvent counted;
   if (p->counts_pinned) {
-    GSR_HIP(hipEventCreateWithFlags(&counted, hipEventDisableTiming));
-    GSR_HIP(hipEventRecord(counted, s));
+    GSR_HIP(hipEventCreateWithFlags(&counted.e, hipEventDisableTiming));
+    GSR_HIP(hipEventRecord(counted.e, s));
   }
   if (p->binning_mode != GSR_BINNING_KEYS64) {
     // first half of the two-level binning needs no host-side count: enqueue it before the read-back so that the
@@ -187,9 +200,8 @@ int gsr_forward_preprocess(const GsrParams* p, void* geom_ws, int32_t* radii, vo
                           at<char>(geom_ws, L.dsort), s, total + 1);
   }
   if (int rc = check(p, s, "depth_sort")) return rc;
-  if (counted) {
-    const hipError_t e = hipEventSynchronize(counted);     // waits for the scan kernel only
-    (void)hipEventDestroy(counted);
+  if (counted.e) {
+    const hipError_t e = hipEventSynchronize(counted.e);     // waits for the scan kernel only
     if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize(counted)");
     *num_rendered = p->counts_pinned[0];
     *num_visible = p->counts_pinned[1];
@@ -353,17 +365,24 @@ int gsr_profile_destroy(void* handle) {
 int gsr_profile_collect(void* handle, double* ms_sum, uint32_t* counts) {
   Profile* pr = static_cast<Profile*>(handle);
   if (!pr || !ms_sum || !counts) return fail(GSR_E_BADARG, "NULL argument");
-  for (auto& sp : pr->used) {
-    if (sp.a && sp.b) {
-      GSR_HIP(hipEventSynchronize(sp.b));
+  std::vector<Profile::Span> spans;
+  {
+    std::lock_guard<std::mutex> lock(pr->mu);
+    spans.swap(pr->used);
+  }
+  hipError_t err = hipSuccess;
+  for (auto& sp : spans) {
+    if (sp.a && sp.b && err == hipSuccess) {
+      err = hipEventSynchronize(sp.b);
       float ms = 0.f;
-      GSR_HIP(hipEventElapsedTime(&ms, sp.a, sp.b));
-      if (sp.stage >= 0 && sp.stage < GSR_STAGE_COUNT) { ms_sum[sp.stage] += ms; counts[sp.stage] += 1; }
+      if (err == hipSuccess) err = hipEventElapsedTime(&ms, sp.a, sp.b);
+      if (err == hipSuccess && sp.stage >= 0 && sp.stage < GSR_STAGE_COUNT) { ms_sum[sp.stage] += ms; counts[sp.stage] += 1; }
     }
+    std::lock_guard<std::mutex> lock(pr->mu);     // the events go back to the pool on every path
     if (sp.a) pr->pool.push_back(sp.a);
     if (sp.b) pr->pool.push_back(sp.b);
   }
-  pr->used.clear();
+  if (err != hipSuccess) return hip_fail(err, "gsr_profile_collect");
   return 0;
 }
 const char* gsr_stage_name(int32_t stage) {
@@ -453,12 +472,13 @@ int gsr_debug_read_image(const void* img_ws, int32_t width, int32_t height, floa
   return 0;
 }
 
+size_t gsr_l1_loss_workspace_bytes(void) { return l1_loss_workspace_bytes(); }
 int gsr_l1_loss_fwd_bwd(const float* x, const float* gt, size_t n, float scale, float* loss_sum, float* dL_dx,
-                        void* stream) {
-  if (!x || !gt || !loss_sum) return fail(GSR_E_BADARG, "NULL input");
+                        void* workspace, void* stream) {
+  if (!x || !gt || !loss_sum || !workspace) return fail(GSR_E_BADARG, "NULL input");
   if ((((uintptr_t)x | (uintptr_t)gt | (uintptr_t)dL_dx) & 15u) != 0) return fail(GSR_E_ALIGN, "16-byte alignment required");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  launch_l1_loss(x, gt, n, scale, loss_sum, dL_dx, s);
+  launch_l1_loss(x, gt, n, scale, loss_sum, dL_dx, static_cast<float*>(workspace), s);
   return check(nullptr, s, "l1_loss");
 }
 

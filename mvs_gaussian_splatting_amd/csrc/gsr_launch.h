@@ -90,8 +90,9 @@ size_t knn_workspace_bytes(int N);
 void launch_knn3(const float* pts, int N, float* mean_dist2, void* ws, hipStream_t s);
 
 // aux.hip
+size_t l1_loss_workspace_bytes();
 void launch_l1_loss(const float* x, const float* gt, size_t n, float scale, float* loss_sum, float* dL_dx,
-                    hipStream_t s);
+                    float* partials, hipStream_t s);
 void launch_densify_stats(int P, const float* dL_dmeans2D, const int32_t* radii, float* accum, float* denom,
                           float* max_radii2D, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* visible, hipStream_t s);

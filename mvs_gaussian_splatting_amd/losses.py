@@ -18,12 +18,13 @@ class _L1Loss(torch.autograd.Function):
         if xc.dtype != torch.float32 or gc.dtype != torch.float32 or xc.shape != gc.shape:
             raise TypeError("l1_loss expects two float32 tensors of the same shape")
         n = xc.numel()
-        loss_sum = torch.zeros(1, dtype=torch.float32, device=x.device)
+        loss_sum = torch.empty(1, dtype=torch.float32, device=x.device)
+        ws = torch.empty(lib.gsr_l1_loss_workspace_bytes(), dtype=torch.uint8, device=x.device)   # block partials
         grad = torch.empty_like(xc)
         with torch.cuda.device(x.device):
             stream = torch.cuda.current_stream(x.device).cuda_stream
             _lib.check(lib.gsr_l1_loss_fwd_bwd(xc.data_ptr(), gc.data_ptr(), n, 1.0 / n, loss_sum.data_ptr(),
-                                               grad.data_ptr(), stream), "gsr_l1_loss_fwd_bwd")
+                                               grad.data_ptr(), ws.data_ptr(), stream), "gsr_l1_loss_fwd_bwd")
         ctx.save_for_backward(grad)
         return (loss_sum / n).reshape(())
 

@@ -47,6 +47,17 @@ def _f32c(t: torch.Tensor, name: str, dev: torch.device, align16: bool = False) 
     return t
 
 
+def _check_rows(t: torch.Tensor, name: str, P: int, *tail) -> None:
+    """The kernels index raw pointers: a non-empty input must be [P, *tail] (tail entry None = any size >= 1)."""
+    if t.numel() == 0:
+        return
+    ok = t.dim() == 1 + len(tail) and t.shape[0] == P and all(
+        (d is None and int(s) >= 1) or (d is not None and int(s) == d) for s, d in zip(t.shape[1:], tail))
+    if not ok:
+        want = ", ".join("M" if d is None else str(d) for d in tail)
+        raise ValueError(f"{name} must have shape [P={P}, {want}], got {list(t.shape)}")
+
+
 def _require_gpu(t: torch.Tensor) -> torch.device:
     if not t.is_cuda:
         raise _lib.GsrError("GaussianRasterizer needs tensors on a ROCm GPU: this build has no CPU path "
@@ -108,7 +119,7 @@ def _make_params(dev, settings: GaussianRasterizationSettings, means3D, sh, colo
     p.opacities, p.scales, p.rotations = _ptr(opacities), _ptr(scales), _ptr(rotations)
     p.cov3D_precomp = _ptr(cov3Ds_precomp)
     p.viewmatrix, p.projmatrix, p.campos, p.bg = view.data_ptr(), proj.data_ptr(), campos.data_ptr(), bg.data_ptr()
-    p.profile = _lib.active_profile_handle()
+    p.profile = _lib.active_profile_handle()      # raw handle; the owning object travels in ctx.profile
     p.shs_rest = _ptr(sh_rest)
     p.act_flags = int(act_flags)
     p.binning_mode = _binning_mode()
@@ -133,6 +144,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         cov3Ds_precomp = _f32c(cov3Ds_precomp, "cov3D_precomp", dev)
         if opacities.numel() != P:
             raise ValueError("opacities must have one value per Gaussian")
+        _check_rows(means3D, "means3D", P, 3)
+        _check_rows(sh, "shs", P, None, 3)
+        _check_rows(colors_precomp, "colors_precomp", P, 3)
+        _check_rows(scales, "scales", P, 3)
+        _check_rows(rotations, "rotations", P, 4)
+        _check_rows(cov3Ds_precomp, "cov3D_precomp", P, 6)
+        if means2D is not None and means2D.numel() and means2D.shape[0] != P:
+            raise ValueError(f"means2D must have one row per Gaussian, got {list(means2D.shape)}")
         H, W = int(raster_settings.image_height), int(raster_settings.image_width)
 
         with torch.cuda.device(dev):
@@ -161,7 +180,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise
 
         ctx.raster_settings = raster_settings
-        ctx.profile = params.profile     # backward runs on an autograd thread: carry the handle explicitly
+        ctx.profile = _lib.active_profile()     # backward runs on an autograd thread: carry the (live) object explicitly
         ctx.num_rendered = R
         ctx.num_visible = V
         ctx.binning_mode = params.binning_mode
@@ -185,7 +204,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         with torch.cuda.device(dev):
             params, keep = _make_params(dev, settings, means3D, sh, colors_precomp, opacities, scales, rotations,
                                         cov3Ds_precomp)
-            params.profile = ctx.profile
+            params.profile = ctx.profile.handle() if ctx.profile is not None else None
             params.binning_mode = ctx.binning_mode
             stream = _stream(dev)
             new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
@@ -233,6 +252,12 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
         raw_rotations = _f32c(raw_rotations, "rotation", dev, align16=True)
         if f_dc.shape[0] != P or f_dc.numel() != 3 * P or f_rest.shape[0] != P or f_rest.shape[1] != 15:
             raise ValueError("fused inputs need f_dc [P,1,3] and f_rest [P,15,3]")
+        _check_rows(means3D, "means3D", P, 3)
+        _check_rows(f_rest, "f_rest", P, 15, 3)
+        _check_rows(raw_scales, "scaling", P, 3)
+        _check_rows(raw_rotations, "rotation", P, 4)
+        if raw_opacity.numel() != P or raw_scales.numel() != 3 * P or raw_rotations.numel() != 4 * P:
+            raise ValueError("fused inputs need opacity [P,1], scaling [P,3] and rotation [P,4]")
         H, W = int(raster_settings.image_height), int(raster_settings.image_width)
         empty = torch.empty(0, dtype=torch.float32, device=dev)
         flags = _lib.ACT_SCALE_EXP | _lib.ACT_ROT_NORMALIZE | _lib.ACT_OPACITY_SIGMOID
@@ -253,7 +278,7 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
             _lib.check(lib.gsr_forward_render(C.byref(params), geom.data_ptr(), binning.data_ptr(), nbytes,
                                               img.data_ptr(), R, V, color.data_ptr(), stream), "gsr_forward_render")
         ctx.raster_settings = raster_settings
-        ctx.profile = params.profile
+        ctx.profile = _lib.active_profile()
         ctx.num_rendered = R
         ctx.num_visible = V
         ctx.binning_mode = params.binning_mode
@@ -276,7 +301,7 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
         with torch.cuda.device(dev):
             params, keep = _make_params(dev, settings, means3D, f_dc, empty, raw_opacity, raw_scales, raw_rotations,
                                         empty, sh_rest=f_rest, act_flags=ctx.act_flags)
-            params.profile = ctx.profile
+            params.profile = ctx.profile.handle() if ctx.profile is not None else None
             params.binning_mode = ctx.binning_mode
             stream = _stream(dev)
             new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731

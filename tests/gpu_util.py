@@ -78,3 +78,33 @@ def forward_with_state(dev, settings, means3D, opacities, shs=None, colors_preco
 def oracle_inputs(model):
     """(means3D, opacity, shs, scales, rotations) exactly as render() hands them to the operator."""
     return model.get_xyz, model.get_opacity, model.get_features, model.get_scaling, model.get_rotation
+
+
+def grads_product(dev, model, settings, target, weight, use_cov=False, use_colors=None):
+    """HIP operator forward + backward of the masked L1 loss of tests/grad_util.py (same leaves, same weights)."""
+    from grad_util import masked_l1
+    from mvs_gaussian_splatting_amd import GaussianRasterizer
+    leaves = {}
+
+    def leaf(name, t):
+        leaves[name] = t.detach().to(dev).requires_grad_(True)
+        return leaves[name]
+
+    xyz = leaf("xyz", model._xyz)
+    op = leaf("opacity", model._opacity)
+    m2 = torch.zeros(xyz.shape[0], 3, device=dev, requires_grad=True)
+    leaves["means2D"] = m2
+    kw = {}
+    if use_colors is not None:
+        kw["colors_precomp"] = leaf("colors", use_colors)
+    else:
+        fdc, fr = leaf("f_dc", model._features_dc), leaf("f_rest", model._features_rest)
+        kw["shs"] = torch.cat((fdc, fr), dim=1)
+    if use_cov:
+        kw["cov3D_precomp"] = leaf("cov3D", model.get_covariance(1.0))
+    else:
+        kw["scales"] = torch.exp(leaf("scaling", model._scaling))
+        kw["rotations"] = torch.nn.functional.normalize(leaf("rotation", model._rotation))
+    col, radii = GaussianRasterizer(settings)(means3D=xyz, means2D=m2, opacities=torch.sigmoid(op), **kw)
+    masked_l1(col, target, weight).backward()
+    return {k: v.grad.detach().cpu() for k, v in leaves.items()}, col.detach().cpu()

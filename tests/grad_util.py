@@ -1,0 +1,100 @@
+"""Gradient parity at the north-star bar (1e-5) without the threshold-fragile pixels.
+
+A pixel whose compositing decisions sit within MARGIN (relative) of a threshold in the float64 oracle (alpha vs 1/255,
+T vs 1e-4), whose float32 evaluation is ill-conditioned (oracle/rasterizer_ref.py: COND_EPS), or whose L1 residual is
+within SIGN_EPS of zero (sign(x - target) may flip) can legitimately decide differently in two correct float32
+implementations.  Instead of loosening the tolerance of every parameter when one such pixel exists, the loss weight of
+exactly those pixels (channels, for the sign) is set to ZERO on both sides:
+
+    loss = sum(weight * |color - target|) / (3 H W),   weight in {0, 1}[3,H,W] derived from the float64 oracle forward
+
+so that what remains is differentiable-identical on both sides and held to 1e-5.
+
+The error measure is per parameter tensor, max-norm relative:  max|got - ref| / max|ref|  (not per element: elements
+whose gradient is 1e-6 of the tensor's largest are compared to the same absolute bar).  The only escape is
+conditioning: where an independent float32 implementation (the oracle itself in float32, same weights) misses 1e-5
+against float64, the bar becomes 2 x that implementation's error.  Both numbers are printed for every tensor.
+"""
+import torch
+
+MARGIN = 1e-4
+SIGN_EPS = 1e-5
+TOL = 1e-5
+
+RAW = ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")
+
+
+def loss_weight(col64, target, margin, tile_mask=None):
+    """{0,1}[3,H,W] float64: zero on fragile pixels / sign-fragile channels (and outside tile_mask)."""
+    w = (margin > MARGIN)[None] & ((col64.detach().double() - target.double()).abs() > SIGN_EPS)
+    if tile_mask is not None:
+        w = w & tile_mask.bool()
+    return w.to(torch.float64)
+
+
+def masked_l1(col, target, weight):
+    return ((col - target.to(col.dtype).to(col.device)).abs() * weight.to(col.dtype).to(col.device)).sum() / weight.numel()
+
+
+def oracle_operator_inputs(model, dtype, use_cov=False, use_colors=None):
+    """Leaves (raw parameters) and the operator kwargs the reference getters would produce from them."""
+    leaves = {}
+
+    def leaf(name, t):
+        leaves[name] = t.detach().to(dtype).requires_grad_(True)
+        return leaves[name]
+
+    xyz = leaf("xyz", model._xyz)
+    op = leaf("opacity", model._opacity)
+    m2 = torch.zeros(xyz.shape[0], 3, dtype=dtype, requires_grad=True)
+    leaves["means2D"] = m2
+    kw = {}
+    if use_colors is not None:
+        kw["colors_precomp"] = leaf("colors", use_colors)
+    else:
+        fdc, fr = leaf("f_dc", model._features_dc), leaf("f_rest", model._features_rest)
+        kw["shs"] = torch.cat((fdc, fr), dim=1)
+    if use_cov:
+        kw["cov3D_precomp"] = leaf("cov3D", model.get_covariance(1.0))
+    else:
+        kw["scales"] = torch.exp(leaf("scaling", model._scaling))
+        kw["rotations"] = torch.nn.functional.normalize(leaf("rotation", model._rotation))
+    return leaves, xyz, m2, torch.sigmoid(op), kw
+
+
+def grads_oracle(model, settings, target, *, dtype=torch.float64, use_cov=False, use_colors=None, weight=None,
+                 tiles=None, tile_mask=None):
+    """Oracle forward + backward of the masked L1 loss.  weight=None: derive it from this run's own forward (the
+    float64 run defines the weights; the float32 run must be given them).  Returns (grads, weight, aux, color)."""
+    from oracle import rasterize_ref
+    leaves, xyz, m2, op, kw = oracle_operator_inputs(model, dtype, use_cov, use_colors)
+    col, radii, aux = rasterize_ref(xyz, m2, op, settings, want_aux=True, want_margin=True, tiles=tiles, **kw)
+    if weight is None:
+        weight = loss_weight(col, target, aux["margin"], tile_mask)
+    masked_l1(col, target, weight).backward()
+    grads = {k: (v.grad.detach() if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
+    return grads, weight, aux, col.detach()
+
+
+def compare_grads(got, ref, ref32=None, label=""):
+    """Assert max|got - ref| / max|ref| <= max(1e-5, 2 e32) for every tensor; print the table that ran."""
+    rows, bad = [], {}
+    for k, r in ref.items():
+        if r.numel() == 0:
+            continue
+        r = r.double()
+        scale = float(r.abs().max())
+        g = got[k].double().cpu()
+        assert torch.isfinite(g).all(), f"{label}: non-finite gradient in {k}"
+        if scale == 0.0:
+            assert float(g.abs().max()) == 0.0, f"{label}: {k} must be all zero"
+            continue
+        e = float((g - r).abs().max()) / scale
+        e32 = float((ref32[k].double() - r).abs().max()) / scale if ref32 is not None else 0.0
+        tol = max(TOL, 2.0 * e32)
+        rows.append(f"{k}: err {e:.2e} (float32 oracle {e32:.2e}, bar {tol:.2e})")
+        if e > tol:
+            bad[k] = (e, e32, tol)
+    print(f"[grad parity] {label}: " + "; ".join(rows))
+    assert not bad, f"{label}: max-norm relative gradient error above the bar: {bad}"
+    return rows

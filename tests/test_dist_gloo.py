@@ -1,4 +1,4 @@
-"""View-sharded step on 2 CPU ranks (gloo).  The driver logic is the product's; the render / loss
+"""View-sharded step on 2 and 4 CPU ranks (gloo).  The driver logic is the product's; the render / loss
 functions are injected with the CPU oracle because the HIP operator has no CPU path."""
 import math
 import os
@@ -55,12 +55,13 @@ def test_views_partition():
     assert views_of_rank(8, 1, 4) == [1, 5]
 
 
-@pytest.mark.timeout(300)
-def test_two_rank_step_matches_single_process():
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,n_views", [(2, 4), (4, 8)])
+def test_multi_rank_step_matches_single_process(world, n_views):
+    """world 2 with 4 views (partition [r, r+2]) and world 4 with 8 views (partition [r, r+4], the C5 shape)."""
     from mvs_gaussian_splatting_amd import dist as gdist
     from mvs_gaussian_splatting_amd.synthetic import PipelineParams
     from oracle import l1_loss_ref
-    n_views = 4
     model, cams, targets = _scene(n_views)
     single = gdist.sharded_train_step(model, cams, targets, torch.zeros(3), PipelineParams(), render_fn=_oracle_render,
                                       loss_fn=l1_loss_ref, stats_fn=None)
@@ -68,17 +69,18 @@ def test_two_rank_step_matches_single_process():
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 1000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_views, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 1000) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_views, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=240) for _ in procs)
+    res = sorted(q.get(timeout=480) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, loss0, views0, mine0, g0), (r1, loss1, views1, mine1, g1) = res
-    assert views0 == views1 == n_views
-    assert mine0 == [0, 2] and mine1 == [1, 3]
-    assert math.isclose(loss0, loss1, rel_tol=1e-6)                 # the all-reduced loss is identical on all ranks
-    assert math.isclose(loss0, single["loss"], rel_tol=1e-5)        # and equals the single-process mean
-    assert g0 > 0 and g1 > 0
+    assert [r[0] for r in res] == list(range(world))
+    for rank, loss, views, mine, g in res:
+        assert views == n_views                                        # the all-reduced view count proves the group size
+        assert mine == list(range(rank, n_views, world))
+        assert math.isclose(loss, res[0][1], rel_tol=1e-6)             # the all-reduced loss is identical on all ranks
+        assert math.isclose(loss, single["loss"], rel_tol=1e-5)        # and equals the single-process mean
+        assert g > 0

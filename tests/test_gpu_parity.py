@@ -8,8 +8,11 @@ Tolerances (BASELINE.json north_star: 1e-5 relative fp32):
   a threshold in the oracle (alpha vs 1/255, T vs 1e-4).  A pixel that sits on a threshold may legitimately
   flip between two float32 exp implementations; those are bounded to a small fraction and to the size of one
   flipped contribution;
-* gradients: against float64 autograd of the oracle, 1e-5 relative to the tensor's max-norm per parameter
-  on a scene where no decision is within the flip margin, else 2e-3 with the flip count reported.
+* gradients: against float64 autograd of the oracle at 1e-5, max-norm relative per parameter tensor
+  (max|got - ref| / max|ref|), UNCONDITIONALLY: the threshold-fragile pixels get loss weight 0 on both sides
+  (tests/grad_util.py) instead of loosening the bar; the only escape is conditioning -- 2 x the error of the
+  oracle itself run in float32 where that independent float32 implementation misses 1e-5.  Every test prints
+  the per-tensor errors that ran.
 """
 import math
 
@@ -127,62 +130,27 @@ def test_empty_and_degenerate_inputs(gpu_device):
     assert int((radii > 0).sum()) > 0 and torch.allclose(col.cpu(), expect)
 
 
-def _grads_product(dev, model, cam, bg, target, deg, use_cov=False, use_colors=None):
-    from mvs_gaussian_splatting_amd import GaussianRasterizer
-    from gpu_util import product_settings
-    st = product_settings(cam, bg, deg, dev)
-    leaves = {}
-    def leaf(name, t):
-        leaves[name] = t.detach().to(dev).requires_grad_(True)
-        return leaves[name]
-    xyz = leaf("xyz", model._xyz)
-    op = leaf("opacity", model._opacity)
-    m2 = torch.zeros(xyz.shape[0], 3, device=dev, requires_grad=True)
-    leaves["means2D"] = m2
-    kw = {}
-    if use_colors is not None:
-        kw["colors_precomp"] = leaf("colors", use_colors)
-    else:
-        fdc, fr = leaf("f_dc", model._features_dc), leaf("f_rest", model._features_rest)
-        kw["shs"] = torch.cat((fdc, fr), dim=1)
-    if use_cov:
-        kw["cov3D_precomp"] = leaf("cov3D", model.get_covariance(1.0))
-    else:
-        kw["scales"] = torch.exp(leaf("scaling", model._scaling))
-        kw["rotations"] = torch.nn.functional.normalize(leaf("rotation", model._rotation))
-    col, radii = GaussianRasterizer(st)(means3D=xyz, means2D=m2, opacities=torch.sigmoid(op), **kw)
-    loss = (col - target.to(dev)).abs().mean()
-    loss.backward()
-    return {k: v.grad.detach().cpu() for k, v in leaves.items()}, col.detach().cpu()
-
-
-def _grads_oracle(model, cam, bg, target, deg, use_cov=False, use_colors=None, dtype=torch.float64):
-    from oracle import rasterize_ref
-    st = make_settings(cam, bg, deg)
-    d = dtype
-    leaves = {}
-    def leaf(name, t):
-        leaves[name] = t.detach().to(d).requires_grad_(True)
-        return leaves[name]
-    xyz = leaf("xyz", model._xyz)
-    op = leaf("opacity", model._opacity)
-    m2 = torch.zeros(xyz.shape[0], 3, dtype=d, requires_grad=True)
-    leaves["means2D"] = m2
-    kw = {}
-    if use_colors is not None:
-        kw["colors_precomp"] = leaf("colors", use_colors)
-    else:
-        fdc, fr = leaf("f_dc", model._features_dc), leaf("f_rest", model._features_rest)
-        kw["shs"] = torch.cat((fdc, fr), dim=1)
-    if use_cov:
-        kw["cov3D_precomp"] = leaf("cov3D", model.get_covariance(1.0))
-    else:
-        kw["scales"] = torch.exp(leaf("scaling", model._scaling))
-        kw["rotations"] = torch.nn.functional.normalize(leaf("rotation", model._rotation))
-    col, radii, aux = rasterize_ref(xyz, m2, torch.sigmoid(op), st, want_aux=True, want_margin=True, **kw)
-    loss = (col - target.to(d)).abs().mean()
-    loss.backward()
-    return {k: v.grad.detach() for k, v in leaves.items()}, aux
+def _masked_grad_parity(dev, model, cam, bg, target, deg, label, use_cov=False, use_colors=None, smod=1.0):
+    """float64 oracle defines the loss weights; float32 oracle bounds the conditioning; HIP must meet the bar."""
+    from gpu_util import grads_product, product_settings
+    from grad_util import grads_oracle, compare_grads
+    st_o = make_settings(cam, bg, deg, scale_modifier=smod)
+    ref, weight, aux, col64 = grads_oracle(model, st_o, target, use_cov=use_cov, use_colors=use_colors)
+    ref32, _, _, _ = grads_oracle(model, st_o, target, dtype=torch.float32, use_cov=use_cov, use_colors=use_colors,
+                                  weight=weight)
+    got, col = grads_product(dev, model, product_settings(cam, bg, deg, dev, scale_modifier=smod), target, weight,
+                             use_cov, use_colors)
+    n_fragile = int((aux["margin"] <= 1e-4).sum())
+    n_masked = int((weight == 0).sum())
+    assert n_masked <= 0.3 * weight.numel(), "the mask must leave most of the image in the loss"
+    compare_grads(got, ref, ref32, f"{label} (fragile pixels {n_fragile}, masked elements {n_masked}/{weight.numel()})")
+    # the z component of the screen-space gradient is never written to
+    assert float(got["means2D"][:, 2].abs().max()) == 0.0
+    for k, r in ref.items():          # every compared tensor carries a real signal
+        if k != "means2D":
+            assert float(r.abs().max()) > 0.0, k
+    assert float(ref["means2D"][:, :2].abs().max()) > 0.0
+    return got, ref, weight, aux
 
 
 @pytest.mark.parametrize("deg,use_cov,colors", [(3, False, False), (1, False, False), (0, True, True)])
@@ -190,21 +158,8 @@ def test_backward_matches_fp64_oracle(gpu_device, deg, use_cov, colors):
     model, cam, _, target = small_scene(P=2500, sh_degree=deg, width=208, height=120, scale=0.06)
     bg = torch.tensor([0.3, 0.1, 0.2])
     use_colors = torch.rand(2500, 3, generator=torch.Generator().manual_seed(3)) if colors else None
-    got, col = _grads_product(gpu_device, model, cam, bg, target, deg, use_cov, use_colors)
-    ref, aux = _grads_oracle(model, cam, bg, target, deg, use_cov, use_colors)
-    n_fragile = int((aux["margin"] <= 1e-4).sum())
-    worst = {}
-    for k in ref:
-        r, g = ref[k], got[k].to(torch.float64)
-        scale = float(r.abs().max())
-        assert scale > 0 or k == "means2D" and False or True
-        worst[k] = float((g - r).abs().max()) / max(scale, 1e-30)
-    # sign(x - target) of the L1 loss and every threshold decision are shared only on robust pixels
-    tol = 1e-5 if n_fragile == 0 else 2e-3
-    bad = {k: v for k, v in worst.items() if v > tol}
-    assert not bad, f"relative-to-max gradient error above {tol} (fragile pixels: {n_fragile}): {bad} / all: {worst}"
-    # the z component of the screen-space gradient is never written to
-    assert float(got["means2D"][:, 2].abs().max()) == 0.0
+    _masked_grad_parity(gpu_device, model, cam, bg, target, deg, f"backward deg={deg} cov={use_cov} colors={colors}",
+                        use_cov, use_colors)
 
 
 def test_fused_raw_parameter_path_matches_unfused_and_oracle(gpu_device):
@@ -212,10 +167,13 @@ def test_fused_raw_parameter_path_matches_unfused_and_oracle(gpu_device):
     pixels and raw-parameter gradients of the getter path / the fp64 oracle."""
     from mvs_gaussian_splatting_amd import render
     from mvs_gaussian_splatting_amd.synthetic import PipelineParams
+    from grad_util import grads_oracle, compare_grads, masked_l1
     dev = gpu_device
     model, cam, _, target = small_scene(P=2500, sh_degree=3, width=208, height=120, scale=0.06)
     bg = torch.tensor([0.3, 0.1, 0.2])
-    ref, aux = _grads_oracle(model, cam, bg, target, 3)
+    st_o = make_settings(cam, bg, 3)
+    ref, weight, aux, _ = grads_oracle(model, st_o, target)
+    ref32, _, _, _ = grads_oracle(model, st_o, target, dtype=torch.float32, weight=weight)
     model.to(dev); cam.to(dev)
     out = {}
     for fused in (True, False):
@@ -225,7 +183,7 @@ def test_fused_raw_parameter_path_matches_unfused_and_oracle(gpu_device):
         pipe = PipelineParams()
         pipe.fuse_activations = fused
         pkg = render(cam, model, pipe, bg.to(dev))
-        (pkg["render"] - target.to(dev)).abs().mean().backward()
+        masked_l1(pkg["render"], target, weight).backward()
         out[fused] = (pkg["render"].detach().cpu(), pkg["radii"].cpu(),
                       {"xyz": model._xyz.grad.cpu(), "f_dc": model._features_dc.grad.cpu(),
                        "f_rest": model._features_rest.grad.cpu(), "opacity": model._opacity.grad.cpu(),
@@ -234,11 +192,8 @@ def test_fused_raw_parameter_path_matches_unfused_and_oracle(gpu_device):
     assert int((out[True][1] != out[False][1]).sum()) <= 2          # expf vs torch.exp may flip a ceil()
     assert float((out[True][0] - out[False][0]).abs().max()) <= 2.0 / 255.0
     n_fragile = int((aux["margin"] <= 1e-4).sum())
-    tol = 1e-5 if n_fragile == 0 else 2e-3
-    for k, r in ref.items():
-        g = out[True][2][k].to(torch.float64)
-        err = float((g - r).abs().max()) / max(float(r.abs().max()), 1e-30)
-        assert err <= tol, (k, err, n_fragile)
+    for fused in (True, False):
+        compare_grads(out[fused][2], ref, ref32, f"render() fused={fused} (fragile pixels {n_fragile})")
 
 
 @pytest.mark.parametrize("n,end_bit", [(1, 45), (63, 45), (4097, 45), (1_000_003, 45), (300_000, 64), (50_000, 17)])
@@ -454,7 +409,6 @@ def test_config_C3_masked_train_step_matches_fp64_oracle(gpu_device):
     path runs the whole frame and must produce the same pixels there and the same parameter gradients."""
     from mvs_gaussian_splatting_amd import render
     from mvs_gaussian_splatting_amd.synthetic import CONFIGS, make_scene, PipelineParams
-    from oracle import rasterize_ref
     import os
     torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
     cfg = CONFIGS["C3"]
@@ -465,17 +419,11 @@ def test_config_C3_masked_train_step_matches_fp64_oracle(gpu_device):
     for t in tiles:
         ty, tx = divmod(t, gx)
         mask[:, ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16] = 1.0
-    # ---- oracle, float64, only the masked tiles ----------------------------------------------------
-    d = torch.float64
-    leaves = {k: getattr(model, k).detach().to(d).requires_grad_(True)
-              for k in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")}
+    # ---- oracle, float64 (defines the loss weights) and float32 (conditioning bound), only the masked tiles ---------
+    from grad_util import grads_oracle, compare_grads, masked_l1
     st = make_settings(cam, bg, cfg.sh_degree)
-    col, radii, aux = rasterize_ref(leaves["_xyz"], None, torch.sigmoid(leaves["_opacity"]), st,
-                                    shs=torch.cat((leaves["_features_dc"], leaves["_features_rest"]), dim=1),
-                                    scales=torch.exp(leaves["_scaling"]),
-                                    rotations=torch.nn.functional.normalize(leaves["_rotation"]),
-                                    tiles=tiles, want_aux=True, want_margin=True)
-    ((col - target.to(d)).abs() * mask.to(d)).sum().div(mask.sum() * 3).backward()
+    ref, weight, aux, col = grads_oracle(model, st, target, tiles=tiles, tile_mask=mask)
+    ref32, _, _, _ = grads_oracle(model, st, target, dtype=torch.float32, tiles=tiles, weight=weight)
     # ---- HIP path, whole frame -------------------------------------------------------------------------
     dev = gpu_device
     model.to(dev); cam.to(dev)
@@ -483,18 +431,17 @@ def test_config_C3_masked_train_step_matches_fp64_oracle(gpu_device):
         p.requires_grad_(True)
     pkg = render(cam, model, PipelineParams(), bg.to(dev))
     img = pkg["render"]
-    ((img - target.to(dev)).abs() * mask.to(dev)).sum().div(mask.sum().to(dev) * 3).backward()
+    masked_l1(img, target, weight).backward()
     m = mask[0].bool()
     robust = (aux["margin"] > 1e-4) & m
-    err = (img.detach().cpu() - col.detach().float()).abs().max(dim=0).values
+    err = (img.detach().cpu() - col.float()).abs().max(dim=0).values
     assert float(err[robust].max()) <= 1e-5
     n_fragile = int(((aux["margin"] <= 1e-4) & m).sum())
-    tol = 1e-5 if n_fragile == 0 else 2e-3
-    for k, leaf in leaves.items():
-        got = getattr(model, k).grad.detach().cpu().to(d)
-        ref = leaf.grad
-        e = float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
-        assert e <= tol, (k, e, n_fragile)
+    got = {"xyz": model._xyz.grad, "f_dc": model._features_dc.grad, "f_rest": model._features_rest.grad,
+           "opacity": model._opacity.grad, "scaling": model._scaling.grad, "rotation": model._rotation.grad,
+           "means2D": pkg["viewspace_points"].grad}
+    compare_grads({k: v.detach().cpu() for k, v in got.items()}, ref, ref32,
+                  f"C3 masked train step ({len(tiles)} tiles, fragile pixels {n_fragile})")
 
 
 @pytest.mark.parametrize("N,kind", [(4, "uniform"), (129, "uniform"), (1000, "uniform"), (200_000, "uniform"),
@@ -588,30 +535,8 @@ def test_rare_branches_forward_and_backward_match_oracle(gpu_device, mode, monke
     assert float(err[robust].max()) <= 1e-5
     assert int((~robust).sum()) <= 0.25 * robust.numel()     # needles make many pixels ill-conditioned in float32
     assert float(err.max()) <= 3.0 / 255.0                   # ... where two float32 orders differ, but boundedly
-    # ---- backward vs float64 autograd --------------------------------------------------------------------------------
-    d = torch.float64
-    leaves = {k: getattr(model, k).detach().to(d).requires_grad_(True)
-              for k in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")}
-    c64, _, a64 = rasterize_ref(leaves["_xyz"], None, torch.sigmoid(leaves["_opacity"]), st_o,
-                                shs=torch.cat((leaves["_features_dc"], leaves["_features_rest"]), 1),
-                                scales=torch.exp(leaves["_scaling"]),
-                                rotations=torch.nn.functional.normalize(leaves["_rotation"]), want_aux=True, want_margin=True)
-    (c64 - target.to(d)).abs().mean().backward()
-    dev = gpu_device
-    gl = {k: getattr(model, k).detach().to(dev).requires_grad_(True) for k in leaves}
-    img, _ = GaussianRasterizer(st)(means3D=gl["_xyz"], means2D=torch.zeros(gl["_xyz"].shape[0], 3, device=dev),
-                                    opacities=torch.sigmoid(gl["_opacity"]),
-                                    shs=torch.cat((gl["_features_dc"], gl["_features_rest"]), 1),
-                                    scales=torch.exp(gl["_scaling"]),
-                                    rotations=torch.nn.functional.normalize(gl["_rotation"]))
-    (img - target.to(dev)).abs().mean().backward()
-    n_fragile = int((a64["margin"] <= 1e-4).sum())
-    tol = 1e-5 if n_fragile == 0 else 5e-3
-    for k in leaves:
-        ref, got = leaves[k].grad, gl[k].grad.cpu().to(d)
-        assert torch.isfinite(got).all(), k
-        e = float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
-        assert e <= tol, (k, e, n_fragile)
+    # ---- backward vs float64 autograd: fragile / ill-conditioned pixels carry no loss, the rest is held to 1e-5 --------
+    _masked_grad_parity(gpu_device, model, cam, bg, target, deg, f"rare branches mode={mode}", smod=smod)
 
 
 def test_debug_mode_synchronises_and_matches(gpu_device, tmp_path, monkeypatch):
@@ -679,22 +604,9 @@ def test_fuzz_random_small_scenes_forward_and_backward(gpu_device, seed):
     err = ((out["color"] - col).abs() / col.abs().clamp(min=1.0)).max(dim=0).values
     assert robust.any() and float(err[robust].max()) <= 1e-5
     assert float(err.max()) <= 3.0 / 255.0
-    # gradients of an L1 loss against the float64 oracle
-    got, _ = _grads_product(gpu_device, model, cam, bg, target, deg)
-    # _grads_product uses scale_modifier 1: compare with an oracle at the same setting
-    ref, aux64 = _grads_oracle(model, cam, bg, target, deg)
-    # an independent float32 implementation (the oracle in float32) bounds what float32 arithmetic can deliver on this
-    # scene: random clouds contain Gaussians whose projection is ill-conditioned enough to miss 1e-5 in ANY float32 code
-    ref32, _ = _grads_oracle(model, cam, bg, target, deg, dtype=torch.float32)
-    n_fragile = int((aux64["margin"] <= 1e-4).sum())
-    for k, r in ref.items():
-        if r.numel() == 0:
-            continue
-        m = max(float(r.abs().max()), 1e-30)
-        e = float((got[k].double() - r).abs().max()) / m
-        e32 = float((ref32[k].double() - r).abs().max()) / m
-        tol = max(1e-5, 2.0 * e32) if n_fragile == 0 else 2e-3
-        assert e <= tol, (k, e, e32, n_fragile, dict(W=W, H=H, deg=deg, P=P, scale=scale))
+    # gradients of the masked L1 loss against the float64 oracle (scale_modifier 1 on both sides)
+    _masked_grad_parity(gpu_device, model, cam, bg, target, deg,
+                        f"fuzz seed={seed} " + str(dict(W=W, H=H, deg=deg, P=P, scale=round(scale, 4))))
 
 
 def test_render_host_modes_and_leaf_reuse(gpu_device):
@@ -761,3 +673,31 @@ def test_forward_only_variant_gives_the_same_image(gpu_device):
     g = _lib.GsrGrads()
     rc = _lib.load().gsr_backward(C.byref(p), None, None, None, None, 0, 0, None, None, 0, C.byref(g), None)
     assert rc != 0 and b"forward_only" in _lib.load().gsr_last_error()
+
+
+def test_operator_rejects_misshaped_inputs(gpu_device):
+    """The drop-in boundary hands raw pointers to the kernels: row counts and trailing dims are checked on the host."""
+    from mvs_gaussian_splatting_amd import GaussianRasterizer
+    from gpu_util import product_settings
+    model, cam, bg, _ = small_scene(P=64, sh_degree=1, width=48, height=32)
+    dev = gpu_device
+    st = product_settings(cam, bg, 1, dev)
+    good = dict(means3D=model.get_xyz.to(dev), means2D=torch.zeros(64, 3, device=dev), opacities=model.get_opacity.to(dev),
+                shs=model.get_features.to(dev), scales=model.get_scaling.to(dev), rotations=model.get_rotation.to(dev))
+    GaussianRasterizer(st)(**good)
+    bad = [("scales", good["scales"][:, :1].contiguous()),                 # isotropic scales [P,1]
+           ("rotations", good["rotations"][:, :3].contiguous()),           # [P,3]
+           ("shs", good["shs"][:32].contiguous()),                         # fewer rows than P
+           ("shs", good["shs"][:, :, :2].contiguous()),                    # last dim 2
+           ("means3D", good["means3D"][:, :2].contiguous()),
+           ("opacities", good["opacities"][:10].contiguous())]
+    for name, t in bad:
+        with pytest.raises(ValueError):
+            GaussianRasterizer(st)(**{**good, name: t})
+    cov = dict(good)
+    del cov["scales"], cov["rotations"]
+    with pytest.raises(ValueError):
+        GaussianRasterizer(st)(cov3D_precomp=torch.zeros(64, 3, 3, device=dev), **cov)      # full matrices, not [P,6]
+    with pytest.raises(ValueError):
+        col = dict(cov); del col["shs"]
+        GaussianRasterizer(st)(cov3D_precomp=torch.zeros(64, 6, device=dev), colors_precomp=torch.zeros(64, 4, device=dev), **col)

@@ -193,3 +193,14 @@ def test_densify_restatement_invariants():
     # max_screen_size None: only the opacity rule prunes
     p2 = densify_and_prune_ref(params, None, accum, denom, radii, pd, thr, min_op, extent, None, noise)[0]
     assert p2["xyz"].shape[0] >= n and float(torch.exp(p2["scaling"]).max()) > 0.1 * extent
+
+
+def test_c_oracle_is_clean_under_asan_and_ubsan():
+    """SURVEY §5 (sanitizers): the plain-C restatement runs its rare-branch driver (oracle/c/sanitize_main.c) under
+    AddressSanitizer + UndefinedBehaviorSanitizer with leaks on, and reproduces the plain build's checksum."""
+    import os
+    import subprocess
+    cdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "c")
+    r = subprocess.run(["make", "-C", cdir, "asan"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "asan/ubsan clean" in r.stdout
