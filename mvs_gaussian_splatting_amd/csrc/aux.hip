@@ -114,7 +114,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void unpack_geom_kernel(int P, const Geo
     rect[4 * i] = vis ? x0 : 0u; rect[4 * i + 1] = vis ? y0 : 0u;
     rect[4 * i + 2] = vis ? x0 + (b.rect_wh & 0xffffu) : 0u; rect[4 * i + 3] = vis ? y0 + (b.rect_wh >> 16) : 0u;
   }
-  if (clamped) clamped[i] = vis ? (g.flags & 7u) : 0u;
+  if (clamped) clamped[i] = vis ? rect_clamp_flags(g.rect_min) : 0u;
 }
 
 

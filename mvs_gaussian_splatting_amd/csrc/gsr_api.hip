@@ -43,7 +43,7 @@ int check(const GsrParams* p, hipStream_t s, const char* where) {
 int validate(const GsrParams* p) {
   if (!p) return fail(GSR_E_BADARG, "params is NULL");
   if (p->P < 0 || p->width <= 0 || p->height <= 0) return fail(GSR_E_BADARG, "bad P / image size");
-  if (p->width > 65535 * TILE || p->height > 65535 * TILE) return fail(GSR_E_BADARG, "image too large");
+  if (p->width > 8191 * TILE || p->height > 8191 * TILE) return fail(GSR_E_BADARG, "image too large (13-bit tile coordinates)");
   if (p->P == 0) return 0;
   if (!p->means3D || !p->opacities || !p->viewmatrix || !p->projmatrix || !p->bg)
     return fail(GSR_E_BADARG, "means3D / opacities / viewmatrix / projmatrix / bg must be non-NULL");

@@ -23,11 +23,17 @@ struct __attribute__((aligned(64))) GeomRec {
   float b, ext_x, ext_y;         // colour, conservative half-extent of the alpha >= 1/255 ellipse
   uint32_t tile_mask;            // which tiles of the rect hold instances (see BinInfo::mask); the per-Gaussian row slot
                                  //  lives in GeomLayout::slot_base (a 4-byte write into these records is a line RMW)
-  uint32_t rect_min;             // tile rect min: x | y << 16
+  uint32_t rect_min;             // tile rect min: x | y << 16 | SH clamp mask (r,g,b) << 29   (x, y < 8192 tiles)
   uint32_t rect_wh;              // tile rect width | height << 16
-  float depth;                   // view-space z
-  uint32_t flags;                // bit0..2: SH clamp mask (r,g,b)
+  // completed-square form of the quadratic: q = cxx (dx + kk dy)^2 + isyy dy^2 -- every term >= 0 in float32, taken
+  // from the covariance rather than from cxx cyy - cxy^2 (which cancels for elongated splats)
+  float kk;                      // cxy / cxx = -cov_xy / cov_yy
+  float isyy;                    // 1 / cov_yy = cyy - cxy^2 / cxx
 };
+constexpr uint32_t RECT_Y_MASK = 0x1fffu;
+__host__ __device__ inline uint32_t rect_min_x(uint32_t rect_min) { return rect_min & 0xffffu; }
+__host__ __device__ inline uint32_t rect_min_y(uint32_t rect_min) { return (rect_min >> 16) & RECT_Y_MASK; }
+__host__ __device__ inline uint32_t rect_clamp_flags(uint32_t rect_min) { return rect_min >> 29; }
 static_assert(sizeof(GeomRec) == 64, "GeomRec must be one cache line");
 
 // Compact per-Gaussian binning input (read by duplicateWithKeys without touching GeomRec).

@@ -255,7 +255,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
             g.tile_mask = full_mask(tiles);
             g.rect_min = (uint32_t)x0 | ((uint32_t)y0 << 16);
             g.rect_wh = (uint32_t)(x1 - x0) | ((uint32_t)(y1 - y0) << 16);
-            g.depth = vz;
+            g.kk = -pr.b / pr.c;
+            g.isyy = 1.0f / pr.c;
             bi.depth = vz;
           }
         }
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
       ext_y = sqrtf(t * pr.c) * 1.0001f + 0.01f;
     }
     g.opacity = op; g.r = rgb[0]; g.g = rgb[1]; g.b = rgb[2];
-    g.ext_x = ext_x; g.ext_y = ext_y; g.flags = flags;
+    g.ext_x = ext_x; g.ext_y = ext_y;
     if (p.binning_mode == GSR_BINNING_TWO_LEVEL_CULLED) {
       // Drop the tiles the alpha >= 1/255 ellipse cannot reach (every pixel of such a tile fails the alpha test anyway):
       //  1. rects of more than 32 tiles shrink to the tiles the ellipse's bounding box overlaps -- upstream's rect is a
@@ -370,6 +371,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
     }
     bi.rect_min = g.rect_min; bi.rect_wh = g.rect_wh;
     bi.mask = g.tile_mask;
+    g.rect_min |= flags << 29;         // the binning copy (bi) stays clean
     rec[idx] = g;
     // large splats are rare: their gradient rows are pre-summed cooperatively by the backward (sum_big_rows_kernel)
     if (tiles > ROWS_COOP) big_list[atomicAdd(big_count, 1u)] = (uint32_t)idx;
@@ -644,7 +646,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(GsrParams p, 
     if (p.shs) {
       float dc[3];
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch) dc[ch] = ((r.flags >> ch) & 1u) ? 0.0f : dcol[ch];
+      for (int ch = 0; ch < 3; ++ch) dc[ch] = ((rect_clamp_flags(r.rect_min) >> ch) & 1u) ? 0.0f : dcol[ch];
       const float dxr = px - p.campos[0], dyr = py - p.campos[1], dzr = pz - p.campos[2];
       const float ln = sqrtf(dxr * dxr + dyr * dyr + dzr * dzr);
       const float x = dxr / ln, y = dyr / ln, z = dzr / ln;

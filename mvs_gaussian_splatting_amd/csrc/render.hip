@@ -1,33 +1,35 @@
 // Per-tile alpha compositing, forward and backward (§8 a10, A.5).
 //
-// CDNA4 mapping (not the upstream 16x16-thread block): ONE 64-lane wavefront owns one 16x16
-// tile and every lane carries four pixels, one in each 8x8 sub-block, so that
-//   * the per-Gaussian record is fetched from LDS once per wave (broadcast read) and amortised
-//     over 256 pixel evaluations instead of 64;
-//   * no workgroup barrier exists at all (a workgroup is a single wave);
-//   * a sub-block whose 64 pixels cannot reach alpha >= 1/255 for a Gaussian is skipped with a
-//     scalar branch: the lane that stages the Gaussian tests the conservative extent of the
-//     alpha >= 1/255 ellipse (GeomRec.ext_x/ext_y) against the four sub-blocks, the wave
-//     ballots the result, and only set bits are visited.  Skipped evaluations would have been
-//     rejected by the alpha test anyway, so results are unchanged.
-// Per-instance gradients are reduced across the wave in registers (DPP) and written as one
-// row per (Gaussian, tile) instance -- no atomics; preprocess_bwd sums the rows per Gaussian.
+// CDNA4 mappings (not the upstream 16x16-thread block).  What drives both: on gfx950 a wave64 v_fma/v_mul/v_add issues
+// every ~2.4 cycles per SIMD, v_cmp / v_cndmask / v_min / v_max every ~4.7, v_exp / v_rcp every ~8.3, SALU every ~4.7,
+// and a half-empty EXEC mask saves nothing (profiles/r02/valu_rate.txt) -- the kernels are bound by VALU issue, so the
+// lever is the number of 64-lane evaluations per (Gaussian, tile) instance and the instructions per evaluation.
+//
+// FORWARD: one 256-lane workgroup per tile; wave w owns the 8x8 sub-block w and each of its four 16-lane groups (a DPP
+// row) owns one 4x4 MINI-BLOCK.  Per round the workgroup stages 256 instances (one per lane) into LDS, the staging lane
+// computes from row spans of the alpha >= 1/255 ellipse which of the tile's 16 mini-blocks the instance can reach, and
+// the instances are compacted -- in list order -- into 16 per-mini-block visit lists (wave-level DPP prefix sums of
+// packed 8-bit counters; no atomics).  Each 16-lane group then walks ITS OWN list: one wave instruction evaluates four
+// different (instance, mini-block) pairs.  A 7x7-pixel footprint costs ~7 groups of 16 lanes instead of ~3.5 sub-blocks
+// of 64.  Skipped pairs would have been rejected pixel by pixel by the alpha test, so results are unchanged.
+//
+// BACKWARD: one wave per tile, four pixels per lane (one per 8x8 sub-block), because the nine per-instance gradient sums
+// must be reduced across the pixels of the tile: per-instance gradients are reduced across the wave in registers (DPP /
+// permlane swaps) and written as one row per (Gaussian, tile) instance -- no atomics; preprocess_bwd sums the rows.
 #include "gsr_common.h"
 #include "gsr_launch.h"
 #include <stdlib.h>
 
 namespace gsr {
 
-constexpr int BATCH = WAVE;   // instances staged per round
-// Tiles are independent and each is owned by one wave; four of them share a 256-lane workgroup only to
-// reach 8 waves per SIMD (a CU holds fewer single-wave workgroups than waves).  No workgroup barrier is
-// used: each wave has its own LDS slice, and LDS operations of one wave execute in order.
+constexpr int BATCH = WAVE;   // instances staged per round of the backward
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr float LOG2E = 1.4426950408889634f;
 
-// What one lane fetches for the instance it stages (GeomRec words 0..11 and, for the backward, 12..13).
+// What one lane fetches for the instance it stages (GeomRec words 0..10, 14..15 and, for the backward, 11..13).
 struct Staged {
   float4 q0, q1, q2;
+  float kk, isyy;
   uint32_t rect_min, rect_wh, slot_base;
 };
 
@@ -46,6 +48,9 @@ __device__ inline void load_staged(const GeomRec* __restrict__ rec, uint32_t id,
     s.q2.y = f[1];
     s.q2.z = f[2];
   }
+  const float2 k = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(rec + id) + 56);
+  s.kk = k.x;
+  s.isyy = k.y;
 }
 
 // Which of the tile's four 8x8 sub-blocks can the Gaussian reach with alpha >= 1/255 (bit k = sub-block k).
@@ -73,183 +78,289 @@ __device__ inline uint32_t subblock_mask(float gx, float gy, float ex, float ey,
   return m;
 }
 
-// LDS image of a staged instance.  The quadratic form is kept pre-scaled by log2(e) so that the
-// exponential is a bare v_exp_f32:  log2e*power = dx*(aq*dx + bq*dy) + cq*dy*dy  with
-// aq = -0.5*log2e*cxx, bq = -log2e*cxy, cq = -0.5*log2e*cyy.
+// LDS image of a staged instance.  The quadratic form is kept as a completed square, pre-scaled by log2(e) so that
+// the exponential is a bare v_exp_f32:
+//    log2(e) * power = nka * u^2 + nkd * dy^2,   u = dx + kk * dy,   (dx, dy) = mean - pixel,
+//    nka = -0.5 log2e cxx,  kk = cxy / cxx,  nkd = -0.5 log2e / cov_yy.
+// Both terms are <= 0 in float32 whatever the rounding, so the reference's "power > 0 -> skip" guard (Appendix A.4)
+// can never fire -- it only ever fired on rounding noise of the expanded form -- and costs no compare here.
 struct LdsRec {
-  float4 A;   // x, y, aq, bq
-  float4 B;   // cq, opacity, r, g
+  float4 A;   // x, y, nka, kk
+  float4 B;   // nkd, opacity, r, g
 };
 __device__ inline void make_lds(const Staged& st, LdsRec& o) {
-  o.A = make_float4(st.q0.x, st.q0.y, (-0.5f * LOG2E) * st.q0.z, -LOG2E * st.q0.w);
-  o.B = make_float4((-0.5f * LOG2E) * st.q1.x, st.q1.y, st.q1.z, st.q1.w);
+  o.A = make_float4(st.q0.x, st.q0.y, (-0.5f * LOG2E) * st.q0.z, st.kk);
+  o.B = make_float4((-0.5f * LOG2E) * st.isyy, st.q1.y, st.q1.z, st.q1.w);
+}
+// the same five operations in the forward and in the backward: both must take the same alpha >= 1/255 decisions
+__device__ __forceinline__ float pair_p2(float dx, float dy, float nka, float kk, float nkd) {
+#pragma clang fp contract(off)
+  const float u = __builtin_fmaf(kk, dy, dx);
+  const float s = nka * u;
+  const float v = (nkd * dy) * dy;
+  return __builtin_fmaf(s, u, v);
 }
 
-// Per-lane pixel state: T > 0 while the pixel is live.  A pixel that saturates keeps its final
-// transmittance with the sign flipped (T < 0; outside the image: T = 0), so every later
-// test_T = T*(1-alpha) <= 0 < 1e-4 keeps it out of the blend without a separate flag.
-template <bool STATS, bool TRACK>
-__device__ __forceinline__ void render_fwd_tile(const int tile, float4* sA, float4* sB, float* sC, int W, int H,
-                                                int grid_x, const uint2* __restrict__ ranges,
-                                                const uint32_t* __restrict__ point_list,
-                                                const GeomRec* __restrict__ rec, const float* __restrict__ bg,
-                                                float* __restrict__ out_color, float* __restrict__ final_T,
-                                                uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_max,
-                                                unsigned long long* __restrict__ stats) {
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int tile_x = tile % grid_x, tile_y = tile / grid_x;
-  const int px0 = tile_x * TILE + (lane & 7), py0 = tile_y * TILE + (lane >> 3);
-  const float tx0 = (float)(tile_x * TILE), ty0 = (float)(tile_y * TILE);
-  float pxf0 = (float)px0, pyf0 = (float)py0;
-  asm volatile("" : "+v"(pxf0), "+v"(pyf0));   // keep them in registers (no per-visit re-conversion)
+// ---- wave-level helpers of the forward --------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_shift_add(uint32_t v) {
+  return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+// inclusive prefix sum over the 64 lanes of a wave; the four bytes of v are independent counters (totals <= 64).
+// Called with all lanes active.
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
+  v = dpp_shift_add<0x111, 0xf>(v);   // row_shr:1
+  v = dpp_shift_add<0x112, 0xf>(v);   // row_shr:2
+  v = dpp_shift_add<0x114, 0xf>(v);   // row_shr:4
+  v = dpp_shift_add<0x118, 0xf>(v);   // row_shr:8: inclusive within each row of 16
+  v = dpp_shift_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v = dpp_shift_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
 
-  float T[4], Cr[4], Cg[4], Cb[4];
-  uint32_t last[4];
-  uint32_t live = 0;   // wave-uniform: bit k set while sub-block k still has a live pixel
+constexpr int QROUND = 256;           // instances staged per round (one per lane of the workgroup)
+constexpr int QLIST = QROUND + 8;     // list capacity: the walk reads up to 3 entries past the longest list
+constexpr int QDUMMY = QROUND;        // LDS slot of the all-zero record the lists are padded with (alpha = 0)
+
+// Mini-block reach mask of one instance: bit 4*r + c <-> the 4x4 pixel block at tile-relative (4c, 4r).
+// The alpha >= 1/255 region is the ellipse q <= t.  Along a pixel row dy its x-extent is
+//    xc(dy) -+ hw(dy),  xc = mx - kk dy,  hw^2 = (t / cxx) * max(0, 1 - (dy / ey)^2)       (ey = sqrt(t cov_yy))
+// and, the region being convex, the leftmost point over a block row [ya, yb] is the smaller of the two end rows
+// unless the ellipse's own leftmost point lies in (or near) the row range, where the global extent ex is taken.
+// Everything is inflated (t by 1.002, half-widths by 0.03 px), so that a dropped pair is a pair every pixel of which
+// fails alpha >= 1/255 in the evaluation's float32 arithmetic.
+__device__ inline uint32_t miniblock_mask(float mx, float my, float cxx, float kk, float isyy, float ex, float ey) {
+  if (ex < 0.0f) return 0u;
+  if (mx + ex < 0.0f || mx - ex > 15.0f || my + ey < 0.0f || my - ey > 15.0f) return 0u;
+  const float t = ey * ey * isyy * 1.002f;                    // >= 2 ln(255 opacity), from the inflated ey
+  const float h2 = t * __builtin_amdgcn_rcpf(cxx) * 1.002f;
+  const float iey = __builtin_amdgcn_rcpf(ey);
+  // rows where the ellipse is widest to the left / right: dy = +-ex * (cov_xy / cov_xx), cov_xy / cov_xx ~ -kk (ey/ex)^2
+  const float dyl = kk * ey * (ey * __builtin_amdgcn_rcpf(ex));
+  const float slack = 0.5f + 0.02f * fabsf(dyl);
+  // x-extent of the region along pixel row `row` (tile-relative)
+  auto span = [&](float row, float& l, float& r) {
+    const float dy = row - my;
+    const float u = dy * iey;
+    const float hw = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - u * u) * h2) + 0.03f;
+    const float xc = mx - kk * dy;
+    l = xc - hw;
+    r = xc + hw;
+  };
+  uint32_t m = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const bool in = (px0 + 8 * (k & 1)) < W && (py0 + 8 * (k >> 1)) < H;
-    T[k] = in ? 1.0f : 0.0f;
-    Cr[k] = Cg[k] = Cb[k] = 0.0f;
-    last[k] = 0;
-    if (__builtin_amdgcn_ballot_w64(in) != 0ull) live |= 1u << k;
+  for (int r = 0; r < 4; ++r) {
+    float la, ra, lb, rb;
+    span((float)(4 * r), la, ra);
+    span((float)(4 * r + 3), lb, rb);
+    const float ya = (float)(4 * r) - my, yb = ya + 3.0f;
+    const bool reached = (yb >= -ey) && (ya <= ey);
+    const bool near_l = (dyl >= ya - slack) && (dyl <= yb + slack);
+    const bool near_r = (-dyl >= ya - slack) && (-dyl <= yb + slack);
+    const float left = near_l ? mx - ex : fminf(la, lb);
+    const float right = near_r ? mx + ex : fmaxf(ra, rb);
+    // block column c holds the pixel centres 4c .. 4c+3
+    const float lo = fmaxf(0.0f, ceilf((left - 3.0f) * 0.25f));
+    const float hi = fminf(3.0f, floorf(right * 0.25f));
+    if (reached && hi >= lo) {
+      const uint32_t cols = (2u << (uint32_t)hi) - (1u << (uint32_t)lo);
+      m |= cols << (4 * r);
+    }
   }
+  return m;
+}
+
+// One (instance, pixel) pair of the forward.  T > 0 while the pixel is live; a pixel that saturates keeps its final
+// transmittance with the sign flipped (outside the image: T = 0), so every later test_T = T (1 - alpha) <= 0 < 1e-4
+// keeps it out of the blend without a separate flag.
+template <bool TRACK, bool CLAMP>
+__device__ __forceinline__ void blend_pair(const float4 a, const float4 b, const float cb, const uint32_t pos1,
+                                           const float pxf, const float pyf, float& T, float& Cr, float& Cg, float& Cb,
+                                           uint32_t& last) {
+  const float dx = a.x - pxf, dy = a.y - pyf;
+  const float p2 = pair_p2(dx, dy, a.z, a.w, b.x);
+  float alpha = b.y * __builtin_amdgcn_exp2f(p2);
+  if (CLAMP) alpha = fminf(ALPHA_MAX, alpha);     // opacity <= 0.99 cannot reach the clamp: exp2(p2 <= 0) <= 1
+  if (alpha >= ALPHA_MIN) {
+    const float test_T = T * (1.0f - alpha);
+    if (!(test_T < T_STOP)) {
+      const float w = alpha * T;
+      Cr = fmaf(b.z, w, Cr);
+      Cg = fmaf(b.w, w, Cg);
+      Cb = fmaf(cb, w, Cb);
+      if (TRACK) last = pos1;
+      T = test_T;
+    } else {
+      T = -fabsf(T);      // saturates here (or is parked already)
+    }
+  }
+}
+
+template <bool TRACK, bool CLAMP>
+__device__ __forceinline__ void walk_lists(const uint16_t* __restrict__ mylist, const uint32_t nmax, const uint32_t base1,
+                                           const float4* sA, const float4* sB, const float* sC, const float pxf,
+                                           const float pyf, float& T, float& Cr, float& Cg, float& Cb, uint32_t& last) {
+  uint32_t slot = mylist[0];
+#pragma unroll 2
+  for (uint32_t i = 0; i < nmax; ++i) {
+    const float4 a = sA[slot];
+    const float4 b = sB[slot];
+    const float cb = sC[slot];
+    const uint32_t pos1 = base1 + slot;
+    slot = mylist[i + 1];
+    blend_pair<TRACK, CLAMP>(a, b, cb, pos1, pxf, pyf, T, Cr, Cg, Cb, last);
+  }
+}
+
+template <bool STATS, bool TRACK>
+__global__ __launch_bounds__(256, 8) void render_fwd_kernel(int W, int H, int grid_x, int num_tiles,
+                                                         const uint32_t* __restrict__ tile_order,
+                                                         const uint2* __restrict__ ranges,
+                                                         const uint32_t* __restrict__ point_list,
+                                                         const GeomRec* __restrict__ rec,
+                                                         const float* __restrict__ bg,
+                                                         float* __restrict__ out_color,
+                                                         float* __restrict__ final_T,
+                                                         uint32_t* __restrict__ n_contrib,
+                                                         uint32_t* __restrict__ tile_max,
+                                                         unsigned long long* __restrict__ stats) {
+  __shared__ float4 sA[QROUND + 1];
+  __shared__ float4 sB[QROUND + 1];
+  __shared__ float sC[QROUND + 4];
+  __shared__ __attribute__((aligned(16))) uint16_t sList[16][QLIST];
+  __shared__ uint4 sCnt[4];             // per wave: counts of the 16 mini-blocks, one byte each
+  __shared__ uint32_t sFlag[2][4];      // [0] any opacity > ALPHA_MAX in the round, [1] tile_max partials
+  (void)num_tiles;
+  const int tid = threadIdx.x;
+  const int lane = tid & (WAVE - 1);
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = lane >> 4, q = lane & 15;
+  const int tile = __builtin_amdgcn_readfirstlane((int)tile_order[blockIdx.x]);
+  const int tile_x = tile % grid_x, tile_y = tile / grid_x;
+  const int bx = 8 * (wid & 1) + 4 * (grp & 1) + (q & 3), by = 8 * (wid >> 1) + 4 * (grp >> 1) + (q >> 2);
+  const int px = tile_x * TILE + bx, py = tile_y * TILE + by;
+  const float tx0 = (float)(tile_x * TILE), ty0 = (float)(tile_y * TILE);
+  const float pxf = (float)px, pyf = (float)py;
+  const bool inside = px < W && py < H;
+
+  float T = inside ? 1.0f : 0.0f, Cr = 0.0f, Cg = 0.0f, Cb = 0.0f;
+  uint32_t last = 0;
 
   const uint2 range = ranges[tile];
-  const uint32_t start = range.x, end = range.y;
-
-  // software pipeline: ids two rounds ahead, records one round ahead.  Every prefetch is issued
-  // unconditionally with a clamped index (lanes past the end re-read the last instance and are masked
-  // by `have`): a conditional overwrite of `st` makes the compiler copy registers right behind the load
-  // and wait for it on the spot.
-  uint32_t id_next = 0;
-  Staged st;
-  st.q0 = st.q1 = st.q2 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (start >= end) live = 0;
-  if (live) {
-    load_staged<false>(rec, point_list[min(start + lane, end - 1)], st);
-    id_next = point_list[min(start + BATCH + lane, end - 1)];
+  const uint32_t start = range.x, len = range.y - range.x;
+  if (tid == 0) {
+    sA[QDUMMY] = make_float4(0.f, 0.f, 0.f, 0.f);
+    sB[QDUMMY] = make_float4(0.f, 0.f, 0.f, 0.f);
+    sC[QDUMMY] = 0.0f;
   }
+  // this 16-lane group's mini-block: row / column of 4x4 blocks inside the tile (bit 4 * blk_r + blk_c of the reach mask)
+  const int blk_r = 2 * (wid >> 1) + (grp >> 1), blk_c = 2 * (wid & 1) + (grp & 1);
+  const uint16_t* mylist = &sList[4 * blk_r + blk_c][0];
+  unsigned long long st_pairs = 0, st_evals = 0;
 
-  uint32_t st_staged = 0, st_visited = 0, st_evals = 0, st_hits = 0;
-  for (uint32_t pos = start; pos < end && live; pos += BATCH) {
-    const bool have = pos + lane < end;
-    if (STATS) st_staged += min((uint32_t)BATCH, end - pos);
-    const uint32_t m = have ? subblock_mask(st.q0.x, st.q0.y, st.q2.y, st.q2.z, st.q0.z, st.q0.w, st.q1.x, st.q1.y, tx0, ty0) : 0u;
+  // software pipeline: the id of the next round's instance is fetched one round ahead
+  uint32_t id_next = len ? point_list[start + min((uint32_t)tid, len - 1)] : 0u;
+  for (uint32_t base = 0; base < len; base += QROUND) {
+    // ---- (a) stage one instance per lane, find the mini-blocks it reaches ------------------------------------
+    const bool have = base + tid < len;
+    Staged st;
+    load_staged<false>(rec, id_next, st);
+    {
+      const uint32_t nb = base + QROUND + tid;
+      id_next = point_list[start + min(nb, len - 1)];
+    }
+    {   // pad every list with the dummy slot (16-byte stores)
+      const uint4 d = make_uint4(QDUMMY * 0x10001u, QDUMMY * 0x10001u, QDUMMY * 0x10001u, QDUMMY * 0x10001u);
+      uint4* l4 = reinterpret_cast<uint4*>(&sList[0][0]);
+      for (int c = tid; c < 16 * QLIST * 2 / 16; c += 256) l4[c] = d;
+    }
     LdsRec lr;
     make_lds(st, lr);
-    __builtin_amdgcn_wave_barrier();   // LDS ops of one wave execute in order: no hardware barrier needed
-    sA[lane] = lr.A;
-    sB[lane] = lr.B;
-    sC[lane] = st.q2.x;
-    __builtin_amdgcn_wave_barrier();
-    // prefetch the next round while this one is composited
-    load_staged<false>(rec, id_next, st);
-    id_next = point_list[min(pos + 2 * BATCH + lane, end - 1)];
-
-    // sub-blocks whose pixels are all parked need no further work; re-derived once per round
+    sA[tid] = lr.A;
+    sB[tid] = lr.B;
+    sC[tid] = st.q2.x;
+    const uint32_t m16 = have ? miniblock_mask(st.q0.x - tx0, st.q0.y - ty0, st.q0.z, st.kk, st.isyy, st.q2.y, st.q2.z) : 0u;
+    // ---- (b) wave-level ranks: four packed registers of four 8-bit counters --------------------------------------
+    uint32_t own[4], incl[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (__builtin_amdgcn_ballot_w64(T[k] > 0.0f) == 0ull) live &= ~(1u << k);
-    if (live == 0u) break;
-
-    unsigned long long nz = __ballot(m != 0u);
-    while (nz) {
-      const int j = __ffsll((long long)nz) - 1;
-      nz &= nz - 1;
-      const uint32_t mj = (uint32_t)__builtin_amdgcn_readlane((int)m, j) & live;
-      if (mj == 0u) continue;
-      const float4 a = sA[j];
-      const float4 b = sB[j];
-      const float cb = sC[j];
-      const uint32_t pos1 = pos - start + (uint32_t)j + 1u;   // 1-based contributor index
-      if (STATS) ++st_visited;
-      const float dx0 = a.x - pxf0, dy0 = a.y - pyf0;
+    for (int r = 0; r < 4; ++r) {
+      own[r] = (((m16 >> (4 * r)) & 0xfu) * 0x00204081u) & 0x01010101u;
+      incl[r] = wave_incl_scan_dpp(own[r]);
+    }
+    if (lane == WAVE - 1) sCnt[wid] = make_uint4(incl[0], incl[1], incl[2], incl[3]);
+    const bool opaque = have && st.q1.y > ALPHA_MAX;
+    const bool wave_opaque = __builtin_amdgcn_ballot_w64(opaque) != 0ull;
+    if (lane == 0) sFlag[0][wid] = wave_opaque ? 1u : 0u;
+    __syncthreads();
+    // ---- (c) list positions = counts of the earlier waves + rank within the wave ---------------------------------
+    {
+      uint32_t offs[4] = {0u, 0u, 0u, 0u};
+      for (int w = 0; w < wid; ++w) {
+        const uint4 c = sCnt[w];
+        offs[0] += c.x; offs[1] += c.y; offs[2] += c.z; offs[3] += c.w;     // <= 192 per byte
+      }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (mj & (1u << k)) {
-          const float dx = (k & 1) ? dx0 - 8.0f : dx0;
-          const float dy = (k >> 1) ? dy0 - 8.0f : dy0;
-          const float t = fmaf(a.w, dy, a.z * dx);
-          const float p2 = fmaf(dx, t, (b.x * dy) * dy);
-          const float alpha = fminf(ALPHA_MAX, b.y * __builtin_amdgcn_exp2f(p2));
-          const bool ok = (p2 <= 0.0f) && (alpha >= ALPHA_MIN);
-          const float test_T = T[k] * (1.0f - alpha);
-          const bool go = ok && !(test_T < T_STOP);
-          if (STATS) { ++st_evals; if (__ballot(ok && T[k] > 0.0f) != 0ull) ++st_hits; }
-          // ok && !go: the pixel saturates here (or is already parked): park it with the sign flipped
-          const float parked = ok ? -fabsf(T[k]) : T[k];
-          if (go) {
-            const float w = alpha * T[k];
-            Cr[k] = fmaf(b.z, w, Cr[k]);
-            Cg[k] = fmaf(b.w, w, Cg[k]);
-            Cb[k] = fmaf(cb, w, Cb[k]);
-            if (TRACK) last[k] = pos1;
-          }
-          T[k] = go ? test_T : parked;
-        }
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t posp = offs[r] + incl[r] - own[r];                   // <= 255 per byte
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if ((m16 >> (4 * r + k)) & 1u) sList[4 * r + k][(posp >> (8 * k)) & 0xffu] = (uint16_t)tid;
       }
     }
+    const bool clamp = (sFlag[0][0] | sFlag[0][1] | sFlag[0][2] | sFlag[0][3]) != 0u;
+    // this lane's list length: mini-block (blk_r, blk_c) = byte blk_c of packed register blk_r
+    uint32_t n_lane = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t* c = reinterpret_cast<const uint32_t*>(&sCnt[w]);
+      n_lane += (c[blk_r] >> (8 * blk_c)) & 0xffu;
+    }
+    const uint32_t nmax = max(max((uint32_t)__builtin_amdgcn_readlane((int)n_lane, 0), (uint32_t)__builtin_amdgcn_readlane((int)n_lane, 16)),
+                              max((uint32_t)__builtin_amdgcn_readlane((int)n_lane, 32), (uint32_t)__builtin_amdgcn_readlane((int)n_lane, 48)));
+    __syncthreads();
+    // ---- (d) every 16-lane group walks its own list --------------------------------------------------------------
+    if (STATS) { st_pairs += (q == 0) ? n_lane : 0u; st_evals += (lane == 0) ? nmax : 0u; }
+    if (clamp) walk_lists<TRACK, true>(mylist, nmax, base + 1u, sA, sB, sC, pxf, pyf, T, Cr, Cg, Cb, last);
+    else       walk_lists<TRACK, false>(mylist, nmax, base + 1u, sA, sB, sC, pxf, pyf, T, Cr, Cg, Cb, last);
+    // ---- (e) stop when every pixel of the tile is parked; also fences the LDS reuse ------------------------------
+    if (__syncthreads_and(!(T > 0.0f))) break;
   }
 
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
   const size_t HW = (size_t)W * H;
-  uint32_t mx = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int px = px0 + 8 * (k & 1), py = py0 + 8 * (k >> 1);
-    if (px < W && py < H) {
-      const float Tf = fabsf(T[k]);
-      const size_t pix = (size_t)py * W + px;
-      out_color[pix] = Cr[k] + Tf * bg0;
-      out_color[HW + pix] = Cg[k] + Tf * bg1;
-      out_color[2 * HW + pix] = Cb[k] + Tf * bg2;
-      if (TRACK) {
-        final_T[pix] = Tf;
-        n_contrib[pix] = last[k];
-        mx = max(mx, last[k]);
-      }
+  if (inside) {
+    const float Tf = fabsf(T);
+    const size_t pix = (size_t)py * W + px;
+    out_color[pix] = Cr + Tf * bg0;
+    out_color[HW + pix] = Cg + Tf * bg1;
+    out_color[2 * HW + pix] = Cb + Tf * bg2;
+    if (TRACK) {
+      final_T[pix] = Tf;
+      n_contrib[pix] = last;
     }
   }
   if (TRACK) {
+    uint32_t mx = inside ? last : 0u;
 #pragma unroll
     for (int d = WAVE / 2; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, WAVE));
-    if (lane == 0) tile_max[tile] = mx;
+    if (lane == 0) sFlag[1][wid] = mx;
+    __syncthreads();
+    if (tid == 0) tile_max[tile] = max(max(sFlag[1][0], sFlag[1][1]), max(sFlag[1][2], sFlag[1][3]));
   }
-  if (STATS && lane == 0) {
-    atomicAdd(&stats[0], (unsigned long long)(end - start));
-    atomicAdd(&stats[1], (unsigned long long)st_staged);
-    atomicAdd(&stats[2], (unsigned long long)st_visited);
-    atomicAdd(&stats[3], (unsigned long long)st_evals);
-    atomicAdd(&stats[4], (unsigned long long)st_hits);
-    atomicAdd(&stats[5], (unsigned long long)mx);
+  if (STATS) {
+    // [0] instances in the tile lists, [1] instances staged, [2] (instance, mini-block) pairs, [3] wave evaluations
+    // (each covers up to four pairs), [5] sum of tile_max
+    st_pairs = (unsigned long long)wave_reduce_add_u32((uint32_t)st_pairs);
+    if (lane == 0) {
+      atomicAdd(&stats[2], st_pairs);
+      atomicAdd(&stats[3], st_evals);
+    }
+    if (tid == 0) {
+      atomicAdd(&stats[0], (unsigned long long)len);
+      atomicAdd(&stats[1], (unsigned long long)min(len, ((len + QROUND - 1) / QROUND) * QROUND));
+      if (TRACK) atomicAdd(&stats[5], (unsigned long long)max(max(sFlag[1][0], sFlag[1][1]), max(sFlag[1][2], sFlag[1][3])));
+    }
   }
-}
-
-// One wave per tile; blockIdx walks the tiles longest-list-first (tile_order), so the hardware
-// dispatcher hands the short tiles to the slots that free up last.
-// TRACK = false (GsrParams.forward_only): nothing the backward needs is tracked or written
-template <bool STATS, bool TRACK>
-__global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE) void render_fwd_kernel(int W, int H, int grid_x, int num_tiles,
-                                                          const uint32_t* __restrict__ tile_order,
-                                                          const uint2* __restrict__ ranges,
-                                                          const uint32_t* __restrict__ point_list,
-                                                          const GeomRec* __restrict__ rec,
-                                                          const float* __restrict__ bg,
-                                                          float* __restrict__ out_color,
-                                                          float* __restrict__ final_T,
-                                                          uint32_t* __restrict__ n_contrib,
-                                                          uint32_t* __restrict__ tile_max,
-                                                          unsigned long long* __restrict__ stats) {
-  __shared__ float4 sA[WAVES_PER_BLOCK][BATCH];
-  __shared__ float4 sB[WAVES_PER_BLOCK][BATCH];
-  __shared__ float sC[WAVES_PER_BLOCK][BATCH];
-  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
-  const int slot = blockIdx.x * WAVES_PER_BLOCK + wid;
-  if (slot >= num_tiles) return;
-  const int tile = __builtin_amdgcn_readfirstlane((int)tile_order[slot]);
-  render_fwd_tile<STATS, TRACK>(tile, sA[wid], sB[wid], sC[wid], W, H, grid_x, ranges, point_list, rec, bg, out_color, final_T, n_contrib,
-                         tile_max, stats);
 }
 
 // ---- wave-wide sums ---------------------------------------------------------------------------
@@ -296,8 +407,10 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, floa
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
   const int px0 = tile_x * TILE + (lane & 7), py0 = tile_y * TILE + (lane >> 3);
   const float tx0 = (float)(tile_x * TILE), ty0 = (float)(tile_y * TILE);
-  float pxf0 = (float)px0, pyf0 = (float)py0;
-  asm volatile("" : "+v"(pxf0), "+v"(pyf0));
+  // pixel coordinates of the lane's four pixels (sub-block k: x index k & 1, y index k >> 1): dx = mean - pixel is formed
+  // by ONE subtraction from the exact integer coordinate, as in the forward and in the reference
+  float pxf0 = (float)px0, pxf1 = (float)(px0 + 8), pyf0 = (float)py0, pyf1 = (float)(py0 + 8);
+  asm volatile("" : "+v"(pxf0), "+v"(pxf1), "+v"(pyf0), "+v"(pyf1));      // keep them in registers
   const size_t HW = (size_t)W * H;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
@@ -324,6 +437,7 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, floa
 
   Staged st;
   st.q0 = st.q1 = st.q2 = make_float4(0.f, 0.f, 0.f, 0.f);
+  st.kk = st.isyy = 0.0f;
   st.rect_min = st.rect_wh = st.slot_base = 0;
   // unconditional, index-clamped staging loads (see the forward kernel): ids two rounds ahead,
   // records one round ahead, walking the list back to front
@@ -348,7 +462,7 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, floa
     const uint32_t m = have ? subblock_mask(st.q0.x, st.q0.y, st.q2.y, st.q2.z, st.q0.z, st.q0.w, st.q1.x, st.q1.y, tx0, ty0) : 0u;
     // gradient-row slot of this instance: the Gaussian's first slot + the rank of this tile among its instances
     const uint32_t rw = st.rect_wh & 0xffffu;
-    const uint32_t bit = ((uint32_t)tile_y - (st.rect_min >> 16)) * rw + ((uint32_t)tile_x - (st.rect_min & 0xffffu));
+    const uint32_t bit = ((uint32_t)tile_y - rect_min_y(st.rect_min)) * rw + ((uint32_t)tile_x - rect_min_x(st.rect_min));
     const uint32_t slot = st.slot_base + bin_rank(st.rect_wh, __float_as_uint(st.q2.w), have ? bit : 0u);
     LdsRec lr;
     make_lds(st, lr);
@@ -380,19 +494,14 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, floa
       //   g_yy = sum h dy^2 with h = opacity*G*dL_dalpha;  g_op = sum G*dL_dalpha;  g_r/g/b = sum alpha*T*dL_dpix
       float g_mx = 0.f, g_my = 0.f, g_xx = 0.f, g_xy = 0.f, g_yy = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
       bool any = false;
-      const float dx0 = a.x - pxf0, dy0 = a.y - pyf0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (mj & (1u << k)) {
-          const float dx = (k & 1) ? dx0 - 8.0f : dx0;
-          const float dy = (k >> 1) ? dy0 - 8.0f : dy0;
-          const float adx = a.z * dx;
-          const float t = fmaf(a.w, dy, adx);
-          const float cdy = b.x * dy;
-          const float p2 = fmaf(dx, t, cdy * dy);
+          const float dx = a.x - ((k & 1) ? pxf1 : pxf0), dy = a.y - ((k >> 1) ? pyf1 : pyf0);
+          const float p2 = pair_p2(dx, dy, a.z, a.w, b.x);
           const float G = __builtin_amdgcn_exp2f(p2);
           const float alpha = fminf(ALPHA_MAX, b.y * G);
-          const bool ok = (pos1 <= last[k]) && (p2 <= 0.0f) && (alpha >= ALPHA_MIN);
+          const bool ok = (pos1 <= last[k]) && (alpha >= ALPHA_MIN);
           if (ok) {
             any = true;
             const float rcp = __builtin_amdgcn_rcpf(1.0f - alpha);
@@ -467,15 +576,15 @@ void launch_render_fwd(int W, int H, const uint2* ranges, const uint32_t* point_
                        const float* bg, float* out_color, float* final_T, uint32_t* n_contrib, uint32_t* tile_max,
                        const uint32_t* tile_order, hipStream_t s, unsigned long long* stats) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-  const int nblk = (gx * gy + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  const int nblk = gx * gy;       // one 256-lane workgroup per tile, longest list first
   if (stats)
-    hipLaunchKernelGGL((render_fwd_kernel<true, true>), dim3(nblk), dim3(WAVES_PER_BLOCK * WAVE), 0, s, W, H, gx, gx * gy, tile_order, ranges,
+    hipLaunchKernelGGL((render_fwd_kernel<true, true>), dim3(nblk), dim3(256), 0, s, W, H, gx, gx * gy, tile_order, ranges,
                        point_list, rec, bg, out_color, final_T, n_contrib, tile_max, stats);
   else if (final_T && n_contrib && tile_max)
-    hipLaunchKernelGGL((render_fwd_kernel<false, true>), dim3(nblk), dim3(WAVES_PER_BLOCK * WAVE), 0, s, W, H, gx, gx * gy, tile_order, ranges,
+    hipLaunchKernelGGL((render_fwd_kernel<false, true>), dim3(nblk), dim3(256), 0, s, W, H, gx, gx * gy, tile_order, ranges,
                        point_list, rec, bg, out_color, final_T, n_contrib, tile_max, stats);
   else      // forward only: no per-pixel state for a backward
-    hipLaunchKernelGGL((render_fwd_kernel<false, false>), dim3(nblk), dim3(WAVES_PER_BLOCK * WAVE), 0, s, W, H, gx, gx * gy, tile_order, ranges,
+    hipLaunchKernelGGL((render_fwd_kernel<false, false>), dim3(nblk), dim3(256), 0, s, W, H, gx, gx * gy, tile_order, ranges,
                        point_list, rec, bg, out_color, final_T, n_contrib, tile_max, stats);
 }
 void launch_render_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
