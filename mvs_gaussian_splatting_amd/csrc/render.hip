@@ -22,6 +22,8 @@
 
 namespace gsr {
 
+constexpr int BATCH = WAVE;   // instances staged per round of the backward
+constexpr int WAVES_PER_BLOCK = 4;
 constexpr float LOG2E = 1.4426950408889634f;
 
 // What one lane fetches for the instance it stages (GeomRec words 0..10, 14..15 and, for the backward, 11..13).
@@ -378,200 +380,85 @@ __global__ __launch_bounds__(256, 8) void render_fwd_kernel(int W, int H, int gr
   }
 }
 
-// ---- backward -------------------------------------------------------------------------------------------------------
-// Same mapping as the forward (workgroup per tile, wave per 8x8 sub-block, 16-lane group per 4x4 mini-block, per-group
-// visit lists), walked back to front.  Each wave instruction evaluates four (instance, mini-block) pairs; the nine
-// gradient sums of a pair are reduced over the 16 lanes of its DPP row by a fold tree (26 VALU operations for all nine
-// values: after every level two half-empty registers are merged into one through a bank-masked DPP move), added into
-// the owning wave's LDS accumulator of the instance, and when the round is over one lane per instance adds the four
-// waves' accumulators in wave order and stores ONE 48-byte row per (Gaussian, tile) instance -- no global atomics,
-// bitwise reproducible; preprocess_bwd sums a Gaussian's rows.
-constexpr int BROUND = 128;            // instances staged per round
-constexpr int BLIST = BROUND + 8;      // the walk reads up to 4 entries past the longest list
-constexpr int BDUMMY = BROUND;
-
-// v + (v moved by a DPP control every lane of which has a valid source: rotations, mirrors, quad permutes);
-// bound_ctrl lets the compiler fold the move into a single v_add_f32_dpp
+// ---- wave-wide sums ---------------------------------------------------------------------------
 template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
+__device__ inline float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
   return v + __int_as_float(moved);
 }
-// lanes of the banks in BANK_MASK (bank = 4 consecutive lanes of a 16-lane row) take b, the others keep a
-template <int BANK_MASK>
-__device__ __forceinline__ float dpp_merge(float a, float b) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(a), __float_as_int(b), 0xE4, 0xf, BANK_MASK, false));
+// every lane ends with the sum over its 16-lane row
+__device__ inline float row_sum16(float v) {
+  v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);   // row_half_mirror
+  v = dpp_add<0x140>(v);   // row_mirror
+  return v;
 }
-// Sums of nine values over each 16-lane row.  Result: n0 banks (0,1,2,3) = sums of (v0, v2, v1, v3), n1 banks = sums of
-// (v4, v6, v5, v7), n2 every bank = sum of v8 (each sum in all four lanes of its bank).
-__device__ __forceinline__ void row_fold9(const float (&v)[9], float& n0, float& n1, float& n2) {
-  float w[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) w[i] = dpp_add<0x128>(v[i]);            // row_ror:8  -> lanes l and l+8 agree
-  float m0 = dpp_merge<0xc>(w[0], w[1]);                              // lanes 0-7: v0, lanes 8-15: v1
-  float m1 = dpp_merge<0xc>(w[2], w[3]);
-  float m2 = dpp_merge<0xc>(w[4], w[5]);
-  float m3 = dpp_merge<0xc>(w[6], w[7]);
-  float m4 = w[8];
-  m0 = dpp_add<0x141>(m0); m1 = dpp_add<0x141>(m1); m2 = dpp_add<0x141>(m2);    // row_half_mirror: lanes i and 7-i
-  m3 = dpp_add<0x141>(m3); m4 = dpp_add<0x141>(m4);
-  n0 = dpp_merge<0xa>(m0, m1);                                        // banks 0,2 from m0 (v0 | v1), banks 1,3 from m1
-  n1 = dpp_merge<0xa>(m2, m3);
-  n2 = m4;
-  n0 = dpp_add<0xB1>(n0); n1 = dpp_add<0xB1>(n1); n2 = dpp_add<0xB1>(n2);      // quad_perm [1,0,3,2]
-  n0 = dpp_add<0x4E>(n0); n1 = dpp_add<0x4E>(n1); n2 = dpp_add<0x4E>(n2);      // quad_perm [2,3,0,1]
+// lanes 0..31 end with x[i] + x[i+32], lanes 32..63 with y[i-32] + y[i]
+__device__ inline float fold32(float x, float y) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-
-// One (instance, pixel) pair of the backward; `acc` is the lane's accumulator row of the instance in its wave's LDS
-// slab and `vsel` the lane's value index inside fold registers n0 / n1 (see row_fold9).
-template <bool CLAMP>
-__device__ __forceinline__ void grad_pair(const float4 a, const float4 b, const float cb, const uint32_t pos1,
-                                          const float pxf, const float pyf, float& T, float& Bk, const float dpr,
-                                          const float dpg, const float dpb, const uint32_t last, float* acc,
-                                          const bool clash, const int sel, const int acc_lane, const int grp) {
-  const float dx = a.x - pxf, dy = a.y - pyf;
-  const float p2 = pair_p2(dx, dy, a.z, a.w, b.x);
-  const float G = __builtin_amdgcn_exp2f(p2);
-  float alpha = b.y * G;
-  if (CLAMP) alpha = fminf(ALPHA_MAX, alpha);
-  const bool ok = (pos1 <= last) && (alpha >= ALPHA_MIN);
-  if (__builtin_amdgcn_ballot_w64(ok) != 0ull) {             // else: nothing to accumulate for any of the four pairs
-    // lanes that do not contribute run the same instructions on G = alpha = 0: every product below is then exactly 0
-    const float Gm = ok ? G : 0.0f;
-    const float am = ok ? alpha : 0.0f;
-    const float rcp = __builtin_amdgcn_rcpf(1.0f - am);
-    if (ok) T *= rcp;                                          // transmittance in front of this instance
-    const float cd = fmaf(cb, dpb, fmaf(b.w, dpg, b.z * dpr));  // c . dL_dpix
-    const float dch = am * T;
-    const float dL_dalpha = fmaf(T, cd, -Bk * rcp);
-    Bk = fmaf(cd, dch, Bk);
-    const float gd = Gm * dL_dalpha;
-    const float h = b.y * gd;
-    const float hx = h * dx, hy = h * dy;
-    // un-scaled sums (constants applied once per row): first moments h dx, h dy (the conic is applied per Gaussian by
-    // preprocess_bwd), second moments h dx^2, h dx dy, h dy^2, G dL_dalpha, alpha T dL_dpix
-    const float v[9] = {hx, hy, hx * dx, hx * dy, hy * dy, gd, dch * dpr, dch * dpg, dch * dpb};
-    float n0, n1, n2;
-    row_fold9(v, n0, n1, n2);
-    // lane j of bank k takes the bank's value of n0 (j = 0), n1 (j = 1), n2 (j = 2, bank 0 only): the nine sums of the
-    // row sit in nine lanes of one register and go out with a single LDS operation
-    const float nn = (sel == 0) ? n0 : (sel == 1 ? n1 : n2);
-    // Plain read-add-write into the wave's own slab (LDS float atomics retire about one lane per cycle per CU: they
-    // cost 0.45 ms at C4).  Two groups of the wave may hold the same instance at the same step (`clash`, found once
-    // per round from the lists): then the groups go one after the other, in group order, so the sums stay bitwise
-    // reproducible.
-    const bool adds = acc_lane >= 0;
-    float* dst = acc + (acc_lane < 0 ? 0 : acc_lane);
-    if (!clash) {
-      if (adds) *dst += nn;
-    } else {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        if (adds && grp == g) *dst += nn;
-        __builtin_amdgcn_wave_barrier();     // LDS operations of one wave execute in order
-      }
-    }
-  }
+// rows (0,1,2,3) end with (x.r0 + x.r1, y.r0 + y.r1, x.r2 + x.r3, y.r2 + y.r3)
+__device__ inline float fold16(float x, float y) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// Wave-wide sums of four values at once: row 0 of the result holds sum(q0), row 1 sum(q2),
+// row 2 sum(q1), row 3 sum(q3) (every lane of the row).  10 VALU ops instead of 24.
+__device__ inline float wave_sum4(float q0, float q1, float q2, float q3) {
+  return row_sum16(fold16(fold32(q0, q1), fold32(q2, q3)));
 }
 
-template <bool CLAMP>
-__device__ __forceinline__ void walk_lists_bwd(const uint16_t* __restrict__ mylist, const uint32_t nmax, const uint32_t base1,
-                                               const char* sA, const char* sB, const char* sC, float* slab,
-                                               const float pxf, const float pyf, float& T, float& Bk, const float dpr,
-                                               const float dpg, const float dpb, const uint32_t last, const int sel,
-                                               const int acc_lane, const int grp, const unsigned long long clash_lo,
-                                               const unsigned long long clash_hi) {
-  auto ldA = [&](uint32_t e) { return *reinterpret_cast<const float4*>(sA + e); };
-  auto ldB = [&](uint32_t e) { return *reinterpret_cast<const float4*>(sB + e); };
-  auto ldC = [&](uint32_t e) { return *reinterpret_cast<const float*>(sC + (e >> 2)); };
-  auto clash_at = [&](uint32_t i) { return (((i < 64u ? clash_lo : clash_hi) >> (i & 63u)) & 1ull) != 0ull; };
-  // unrolled by hand (the compiler does not unroll a loop with convergent operations): two pairs per trip, records
-  // one pair ahead; an odd tail lands on the dummy entry the lists are padded with
-  uint32_t e0 = mylist[0], e1 = mylist[1];
-  float4 a0 = ldA(e0), b0 = ldB(e0);
-  float c0 = ldC(e0);
-  for (uint32_t i = 0; i < nmax; i += 2) {
-    const float4 a1 = ldA(e1), b1 = ldB(e1);
-    const float c1 = ldC(e1);
-    const uint32_t e2 = mylist[i + 2], e3 = mylist[i + 3];
-    grad_pair<CLAMP>(a0, b0, c0, base1 + (e0 >> 4), pxf, pyf, T, Bk, dpr, dpg, dpb, last, slab + 9 * (e0 >> 4), clash_at(i), sel, acc_lane, grp);
-    a0 = ldA(e2); b0 = ldB(e2); c0 = ldC(e2);
-    grad_pair<CLAMP>(a1, b1, c1, base1 + (e1 >> 4), pxf, pyf, T, Bk, dpr, dpg, dpb, last, slab + 9 * (e1 >> 4), clash_at(i + 1), sel, acc_lane, grp);
-    e0 = e2;
-    e1 = e3;
-  }
-}
-
-__global__ __launch_bounds__(256) void render_bwd_kernel(int W, int H, int grid_x, int num_tiles,
-                                                         const uint32_t* __restrict__ tile_order,
-                                                         const uint2* __restrict__ ranges,
-                                                         const uint32_t* __restrict__ point_list,
-                                                         const GeomRec* __restrict__ rec,
-                                                         const uint32_t* __restrict__ slot_base,
-                                                         const float* __restrict__ bg,
-                                                         const float* __restrict__ final_T,
-                                                         const uint32_t* __restrict__ n_contrib,
-                                                         const uint32_t* __restrict__ tile_max,
-                                                         const float* __restrict__ dL_dpix,
-                                                         GradRow* __restrict__ rows,
-                                                         uint8_t* __restrict__ row_flags) {
-  __shared__ float4 sA[BROUND + 1];
-  __shared__ float4 sB[BROUND + 1];
-  __shared__ float sC[BROUND + 4];
-  __shared__ uint32_t sSlot[BROUND];                      // gradient-row slot of the staged instance
-  __shared__ __attribute__((aligned(16))) uint16_t sList[16][BLIST];
-  __shared__ __attribute__((aligned(16))) float sAcc[4][BROUND + 1][9];    // per wave: nine sums per staged instance (+ the dummy's)
-  __shared__ uint4 sCnt[2];                               // the two staging waves' counts of the 16 mini-blocks
-  __shared__ uint32_t sFlag[2];
-  (void)num_tiles;
-  const int tid = threadIdx.x;
-  const int lane = tid & (WAVE - 1);
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = lane >> 4, q = lane & 15;
-  const int tile = __builtin_amdgcn_readfirstlane((int)tile_order[blockIdx.x]);
+__device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, float4* sB, float* sC, int W, int H,
+                                                int grid_x, const uint2* __restrict__ ranges,
+                                                const uint32_t* __restrict__ point_list,
+                                                const GeomRec* __restrict__ rec,
+                                                const uint32_t* __restrict__ slot_base, const float* __restrict__ bg,
+                                                const float* __restrict__ final_T,
+                                                const uint32_t* __restrict__ n_contrib,
+                                                const uint32_t* __restrict__ tile_max,
+                                                const float* __restrict__ dL_dpix, GradRow* __restrict__ rows,
+                                                uint8_t* __restrict__ row_flags) {
+  const int lane = threadIdx.x & (WAVE - 1);
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
-  const int blk_r = 2 * (wid >> 1) + (grp >> 1), blk_c = 2 * (wid & 1) + (grp & 1);
-  const int px = tile_x * TILE + 4 * blk_c + (q & 3), py = tile_y * TILE + 4 * blk_r + (q >> 2);
+  const int px0 = tile_x * TILE + (lane & 7), py0 = tile_y * TILE + (lane >> 3);
   const float tx0 = (float)(tile_x * TILE), ty0 = (float)(tile_y * TILE);
-  const float pxf = (float)px, pyf = (float)py;
-  const bool inside = px < W && py < H;
+  // pixel coordinates of the lane's four pixels (sub-block k: x index k & 1, y index k >> 1): dx = mean - pixel is formed
+  // by ONE subtraction from the exact integer coordinate, as in the forward and in the reference
+  float pxf0 = (float)px0, pxf1 = (float)(px0 + 8), pyf0 = (float)py0, pyf1 = (float)(py0 + 8);
+  asm volatile("" : "+v"(pxf0), "+v"(pxf1), "+v"(pyf0), "+v"(pyf1));      // keep them in registers
   const size_t HW = (size_t)W * H;
-  const size_t pix = (size_t)py * W + px;
+  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
-  // per pixel: T (running transmittance in front of the current instance), Bk = sum over the instances behind of
-  // (c . dL_dpix) alpha T  +  T_final (bg . dL_dpix)
-  float T = inside ? final_T[pix] : 0.0f;
-  const uint32_t last = inside ? n_contrib[pix] : 0u;
-  const float dpr = inside ? dL_dpix[pix] : 0.0f;
-  const float dpg = inside ? dL_dpix[HW + pix] : 0.0f;
-  const float dpb = inside ? dL_dpix[2 * HW + pix] : 0.0f;
-  float Bk = T * (bg[0] * dpr + bg[1] * dpg + bg[2] * dpb);
+  // per pixel: T (running transmittance in front of the current instance), Bk = sum over the
+  // instances behind of (c.dL_dpix)*alpha*T  +  T_final*(bg.dL_dpix)
+  float T[4], Bk[4], dpr[4], dpg[4], dpb[4];
+  uint32_t last[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int px = px0 + 8 * (k & 1), py = py0 + 8 * (k >> 1);
+    const bool in = px < W && py < H;
+    const size_t pix = (size_t)py * W + px;
+    T[k] = in ? final_T[pix] : 0.0f;
+    last[k] = in ? n_contrib[pix] : 0u;
+    dpr[k] = in ? dL_dpix[pix] : 0.0f;
+    dpg[k] = in ? dL_dpix[HW + pix] : 0.0f;
+    dpb[k] = in ? dL_dpix[2 * HW + pix] : 0.0f;
+    Bk[k] = T[k] * (bg0 * dpr[k] + bg1 * dpg[k] + bg2 * dpb[k]);
+  }
 
   const uint2 range = ranges[tile];
   const uint32_t start = range.x;
-  const uint32_t hi = min(range.y - range.x, tile_max[tile]);   // instances past the last contributor get no gradient
-  if (tid == 0) {
-    sA[BDUMMY] = make_float4(0.f, 0.f, 0.f, 0.f);
-    sB[BDUMMY] = make_float4(0.f, 0.f, 0.f, 0.f);
-    sC[BDUMMY] = 0.0f;
-  }
-  const uint16_t* mylist = &sList[4 * blk_r + blk_c][0];
-  float* slab = &sAcc[wid][0][0];
-  // where this lane's fold results go (row_fold9): banks (0,1,2,3) of n0 / n1 hold values (0,2,1,3) (+4)
-  const int bank = q >> 2, sel = q & 3;
-  const int vsel = (bank == 1) ? 2 : (bank == 2 ? 1 : bank);
-  // accumulator entry this lane adds to: n0 -> values 0..3, n1 -> 4..7, n2 -> 8 (bank 0 only); -1: none
-  const int acc_lane = sel == 0 ? vsel : (sel == 1 ? 4 + vsel : ((sel == 2 && bank == 0) ? 8 : -1));
-  const bool stager = tid < BROUND;                         // waves 0 and 1 stage one instance per lane
+  uint32_t hi = min(range.y - range.x, tile_max[tile]);   // instances past the last contributor get no gradient
 
-  // rounds of BROUND list positions, back to front; ids are fetched two rounds ahead, GeomRec lines one round ahead
-  const int nrounds = (int)((hi + BROUND - 1) / BROUND);
   Staged st;
   st.q0 = st.q1 = st.q2 = make_float4(0.f, 0.f, 0.f, 0.f);
   st.kk = st.isyy = 0.0f;
   st.rect_min = st.rect_wh = st.slot_base = 0;
-  uint32_t id_next = 0;
-  auto pos_of = [&](int round) { return min((uint32_t)(round < 0 ? 0 : round) * BROUND + (uint32_t)tid, hi - 1); };
+  // unconditional, index-clamped staging loads (see the forward kernel): ids two rounds ahead,
+  // records one round ahead, walking the list back to front
+  auto load_id = [&](uint32_t lo, uint32_t top) { return point_list[start + min(lo + lane, top - 1)]; };
   auto load_rec = [&](uint32_t id) {
     load_staged<true>(rec, id, st);          // q2.w = tile_mask
     st.slot_base = slot_base[id];
@@ -579,116 +466,129 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(int W, int H, int grid_
     st.rect_min = rr.x;
     st.rect_wh = rr.y;
   };
-  if (hi > 0 && stager) {
-    load_rec(point_list[start + pos_of(nrounds - 1)]);
-    id_next = point_list[start + pos_of(nrounds - 2)];
+  uint32_t lo = hi > BATCH ? hi - BATCH : 0u;
+  uint32_t id_next = 0;
+  if (hi > 0) {
+    load_rec(load_id(lo, hi));
+    const uint32_t lo2 = lo > BATCH ? lo - BATCH : 0u;
+    id_next = load_id(lo2, max(lo, 1u));
   }
-  for (int round = nrounds - 1; round >= 0; --round) {
-    const uint32_t base = (uint32_t)round * BROUND;
-    // ---- (a) stage, cull, zero the accumulators, pad the lists ----------------------------------------------------
-    const bool have = stager && base + tid < hi;
-    {
-      const uint4 d = make_uint4(16u * BDUMMY * 0x10001u, 16u * BDUMMY * 0x10001u, 16u * BDUMMY * 0x10001u, 16u * BDUMMY * 0x10001u);
-      uint4* l4 = reinterpret_cast<uint4*>(&sList[0][0]);
-      for (int c = tid; c < 16 * BLIST * 2 / 16; c += 256) l4[c] = d;
-      float4* a4 = reinterpret_cast<float4*>(&sAcc[0][0][0]);
-      for (int c = tid; c < 4 * (BROUND + 1) * 9 / 4; c += 256) a4[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    uint32_t m16 = 0;
-    bool opaque = false;
-    if (stager) {
-      LdsRec lr;
-      make_lds(st, lr);
-      sA[tid] = lr.A;
-      sB[tid] = lr.B;
-      sC[tid] = st.q2.x;
-      // gradient-row slot of this instance: the Gaussian's first slot + the rank of this tile among its instances
-      const uint32_t rw = st.rect_wh & 0xffffu;
-      const uint32_t bit = ((uint32_t)tile_y - rect_min_y(st.rect_min)) * rw + ((uint32_t)tile_x - rect_min_x(st.rect_min));
-      sSlot[tid] = st.slot_base + bin_rank(st.rect_wh, __float_as_uint(st.q2.w), have ? bit : 0u);
-      if (have) m16 = miniblock_mask(st.q0.x - tx0, st.q0.y - ty0, st.q0.z, st.kk, st.isyy, st.q2.y, st.q2.z);
-      opaque = have && lr.B.y > ALPHA_MAX;
-    }
-    // ---- (b) ranks within the wave (waves 2, 3 hold empty masks) --------------------------------------------------
-    uint32_t own[4], incl[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      own[r] = (((m16 >> (4 * r)) & 0xfu) * 0x00204081u) & 0x01010101u;
-      incl[r] = wave_incl_scan_dpp(own[r]);
-    }
-    if (stager && lane == WAVE - 1) sCnt[wid] = make_uint4(incl[0], incl[1], incl[2], incl[3]);
-    const bool wave_opaque = __builtin_amdgcn_ballot_w64(opaque) != 0ull;
-    if (stager && lane == 0) sFlag[wid] = wave_opaque ? 1u : 0u;
-    __syncthreads();
-    // ---- (c) lists in REVERSE list order: position = total - 1 - (earlier wave's count + rank) ----------------------
-    const uint4 c0 = sCnt[0], c1 = sCnt[1];
-    {
-      const uint32_t tot[4] = {c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w};     // <= 128 per byte
-      const uint32_t offs[4] = {wid ? c0.x : 0u, wid ? c0.y : 0u, wid ? c0.z : 0u, wid ? c0.w : 0u};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const uint32_t fwd = offs[r] + incl[r] - own[r];                                 // forward position, per byte
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if ((m16 >> (4 * r + k)) & 1u)
-            sList[4 * r + k][((tot[r] >> (8 * k)) & 0xffu) - 1u - ((fwd >> (8 * k)) & 0xffu)] = (uint16_t)(16 * tid);
-      }
-    }
-    const bool clamp = (sFlag[0] | sFlag[1]) != 0u;
-    const uint32_t* c0w = reinterpret_cast<const uint32_t*>(&c0);
-    const uint32_t* c1w = reinterpret_cast<const uint32_t*>(&c1);
-    const uint32_t n_lane = ((c0w[blk_r] >> (8 * blk_c)) & 0xffu) + ((c1w[blk_r] >> (8 * blk_c)) & 0xffu);
-    const uint32_t nmax = max(max((uint32_t)__builtin_amdgcn_readlane((int)n_lane, 0), (uint32_t)__builtin_amdgcn_readlane((int)n_lane, 16)),
-                              max((uint32_t)__builtin_amdgcn_readlane((int)n_lane, 32), (uint32_t)__builtin_amdgcn_readlane((int)n_lane, 48)));
-    // gathers of the next (earlier) round
-    const uint32_t my_slot = stager ? sSlot[tid] : 0u;
-    const bool staged_any = m16 != 0u;
-    if (stager && round > 0) {
+
+  while (hi > 0) {
+    const bool have = lo + lane < hi;
+    uint32_t m = have ? subblock_mask(st.q0.x, st.q0.y, st.q2.y, st.q2.z, st.q0.z, st.q0.w, st.q1.x, st.q1.y, tx0, ty0) : 0u;
+    if (st.q1.y > ALPHA_MAX) m |= m ? 16u : 0u;      // bit 4: the 0.99 clamp can be reached (opacity <= 0.99: exp2(p2 <= 0) <= 1)
+    // gradient-row slot of this instance: the Gaussian's first slot + the rank of this tile among its instances
+    const uint32_t rw = st.rect_wh & 0xffffu;
+    const uint32_t bit = ((uint32_t)tile_y - rect_min_y(st.rect_min)) * rw + ((uint32_t)tile_x - rect_min_x(st.rect_min));
+    const uint32_t slot = st.slot_base + bin_rank(st.rect_wh, __float_as_uint(st.q2.w), have ? bit : 0u);
+    LdsRec lr;
+    make_lds(st, lr);
+    __builtin_amdgcn_wave_barrier();
+    sA[lane] = lr.A;
+    sB[lane] = lr.B;
+    sC[lane] = st.q2.x;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t cur_lo = lo;
+    hi = lo;
+    lo = hi > BATCH ? hi - BATCH : 0u;
+    {   // prefetch: record of the next (earlier) round, ids of the one after it
       load_rec(id_next);
-      id_next = point_list[start + pos_of(round - 2)];
+      const uint32_t lo2 = lo > BATCH ? lo - BATCH : 0u;
+      id_next = load_id(lo2, max(lo, 1u));
     }
-    __syncthreads();
-    // steps at which two of this wave's four lists hold the same instance (lane i looks at step i and at step 64 + i)
-    unsigned long long clash_lo, clash_hi;
-    {
-      const uint16_t* l0 = &sList[4 * (2 * (wid >> 1)) + 2 * (wid & 1)][0];       // mini-blocks (r, c), (r, c+1),
-      const uint16_t* l1 = l0 + BLIST;                                              // (r+1, c), (r+1, c+1)
-      const uint16_t* l2 = l0 + 4 * BLIST;
-      const uint16_t* l3 = l2 + BLIST;
-      auto clash_step = [&](int i) {
-        const uint32_t a = l0[i], b = l1[i], c = l2[i], d = l3[i];
-        const uint32_t dm = 16u * BDUMMY;
-        return (a != dm && (a == b || a == c || a == d)) || (b != dm && (b == c || b == d)) || (c != dm && c == d);
-      };
-      clash_lo = __builtin_amdgcn_ballot_w64(clash_step(lane));
-      clash_hi = __builtin_amdgcn_ballot_w64(clash_step(64 + lane));
-    }
-    // ---- (d) every 16-lane group walks its own list, back to front -------------------------------------------------
-    if (clamp) walk_lists_bwd<true>(mylist, nmax, base + 1u, (const char*)sA, (const char*)sB, (const char*)sC, slab, pxf, pyf, T,
-                                    Bk, dpr, dpg, dpb, last, sel, acc_lane, grp, clash_lo, clash_hi);
-    else       walk_lists_bwd<false>(mylist, nmax, base + 1u, (const char*)sA, (const char*)sB, (const char*)sC, slab, pxf, pyf, T,
-                                     Bk, dpr, dpg, dpb, last, sel, acc_lane, grp, clash_lo, clash_hi);
-    __syncthreads();
-    // ---- (e) one row per staged instance: the four waves' sums in wave order -----------------------------------------
-    if (staged_any) {
-      float s9[9];
-      bool nz = false;
+
+    unsigned long long nz = __ballot(m != 0u);
+    while (nz) {
+      const int j = 63 - __clzll((long long)nz);   // back to front
+      nz &= ~(1ull << j);
+      const uint32_t mj = (uint32_t)__builtin_amdgcn_readlane((int)m, j);
+      const float4 a = sA[j];
+      const float4 b = sB[j];
+      const float cb = sC[j];
+      const uint32_t pos1 = cur_lo + (uint32_t)j + 1u;
+      // per-lane partial sums over the sub-blocks; un-scaled forms (constants applied after the reduction):
+      //   g_mx = sum h dx, g_my = sum h dy (first moments), g_xx = sum h dx^2, g_xy = sum h dx dy,
+      //   g_yy = sum h dy^2 with h = opacity*G*dL_dalpha;  g_op = sum G*dL_dalpha;  g_r/g/b = sum alpha*T*dL_dpix
+      float g_mx = 0.f, g_my = 0.f, g_xx = 0.f, g_xy = 0.f, g_yy = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
+      bool any = false;
 #pragma unroll
-      for (int v = 0; v < 9; ++v) {
-        s9[v] = ((sAcc[0][tid][v] + sAcc[1][tid][v]) + sAcc[2][tid][v]) + sAcc[3][tid][v];
-        nz = nz || s9[v] != 0.0f;
+      for (int k = 0; k < 4; ++k) {
+        if (mj & (1u << k)) {
+          const float dx = a.x - ((k & 1) ? pxf1 : pxf0), dy = a.y - ((k >> 1) ? pyf1 : pyf0);
+          const float p2 = pair_p2(dx, dy, a.z, a.w, b.x);
+          const float G = __builtin_amdgcn_exp2f(p2);
+          float alpha = b.y * G;
+          if (mj & 16u) alpha = fminf(ALPHA_MAX, alpha);
+          const bool ok = (pos1 <= last[k]) && (alpha >= ALPHA_MIN);
+          if (ok) {
+            any = true;
+            const float rcp = __builtin_amdgcn_rcpf(1.0f - alpha);
+            T[k] *= rcp;                                   // transmittance in front of this instance
+            const float cd = fmaf(cb, dpb[k], fmaf(b.w, dpg[k], b.z * dpr[k]));   // c . dL_dpix
+            const float dch = alpha * T[k];
+            const float dL_dalpha = fmaf(T[k], cd, -Bk[k] * rcp);
+            Bk[k] = fmaf(cd, dch, Bk[k]);
+            g_r = fmaf(dch, dpr[k], g_r);
+            g_g = fmaf(dch, dpg[k], g_g);
+            g_b = fmaf(dch, dpb[k], g_b);
+            const float gd = G * dL_dalpha;
+            g_op += gd;
+            const float h = b.y * gd;
+            const float hx = h * dx, hy = h * dy;
+            g_mx += hx;                                    // first moments; the conic is applied per Gaussian
+            g_my += hy;                                    // by preprocess_bwd
+            g_xx = fmaf(hx, dx, g_xx);
+            g_xy = fmaf(hx, dy, g_xy);
+            g_yy = fmaf(hy, dy, g_yy);
+          }
+        }
       }
-      if (nz) {
-        float4* dst = reinterpret_cast<float4*>(rows + my_slot);
-        dst[0] = make_float4(s9[0], s9[1], -0.5f * s9[2], -s9[3]);      // Mx, My (first moments), dcxx, dcxy
-        dst[1] = make_float4(-0.5f * s9[4], s9[5], s9[6], s9[7]);       // dcyy, dop, dr, dg
-        dst[2] = make_float4(s9[8], 0.f, 0.f, 0.f);                     // db
-        row_flags[my_slot] = 1;
+      if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+        const float s0 = wave_sum4(g_mx, g_xx, g_my, g_xy);   // rows: mx, my, xx, xy
+        const float s1 = wave_sum4(g_yy, g_r, g_op, g_g);     // rows: yy, op, r, g
+        const float s2 = row_sum16(fold16(fold32(g_b, g_b), 0.0f));   // row 0 (and 2): b
+        const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)slot, j);
+        float* dst = reinterpret_cast<float*>(rows + sj);
+        if ((lane & 15) == 0) {
+          const int r = lane >> 4;
+          const float f0 = r < 2 ? 1.0f : (r == 2 ? -0.5f : -1.0f);
+          dst[r] = s0 * f0;                                    // Mx, My (first moments), dcxx, dcxy
+          const float f1 = r == 0 ? -0.5f : 1.0f;
+          dst[4 + r] = s1 * f1;                                // dcyy, dop, dr, dg
+          if (r == 0) {
+            dst[8] = s2;
+            row_flags[sj] = 1;
+          }
+        }
       }
     }
-    // the next round's prefill comes after this read of sAcc: one more barrier
-    __syncthreads();
   }
+}
+
+__global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE, 6) void render_bwd_kernel(int W, int H, int grid_x, int num_tiles,
+                                                          const uint32_t* __restrict__ tile_order,
+                                                          const uint2* __restrict__ ranges,
+                                                          const uint32_t* __restrict__ point_list,
+                                                          const GeomRec* __restrict__ rec,
+                                                          const uint32_t* __restrict__ slot_base,
+                                                          const float* __restrict__ bg,
+                                                          const float* __restrict__ final_T,
+                                                          const uint32_t* __restrict__ n_contrib,
+                                                          const uint32_t* __restrict__ tile_max,
+                                                          const float* __restrict__ dL_dpix,
+                                                          GradRow* __restrict__ rows,
+                                                          uint8_t* __restrict__ row_flags) {
+  __shared__ float4 sA[WAVES_PER_BLOCK][BATCH];
+  __shared__ float4 sB[WAVES_PER_BLOCK][BATCH];
+  __shared__ float sC[WAVES_PER_BLOCK][BATCH];
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+  const int slot = blockIdx.x * WAVES_PER_BLOCK + wid;
+  if (slot >= num_tiles) return;
+  const int tile = __builtin_amdgcn_readfirstlane((int)tile_order[slot]);
+  render_bwd_tile(tile, sA[wid], sB[wid], sC[wid], W, H, grid_x, ranges, point_list, rec, slot_base, bg, final_T, n_contrib,
+                  tile_max, dL_dpix,
+                  rows, row_flags);
 }
 
 void launch_render_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
@@ -711,7 +611,8 @@ void launch_render_bwd(int W, int H, const uint2* ranges, const uint32_t* point_
                        const float* dL_dpix, GradRow* rows, uint8_t* row_flags, const uint32_t* tile_order,
                        hipStream_t s) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-  hipLaunchKernelGGL(render_bwd_kernel, dim3(gx * gy), dim3(256), 0, s, W, H, gx, gx * gy, tile_order, ranges, point_list, rec,
+  const int nblk = (gx * gy + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  hipLaunchKernelGGL(render_bwd_kernel, dim3(nblk), dim3(WAVES_PER_BLOCK * WAVE), 0, s, W, H, gx, gx * gy, tile_order, ranges, point_list, rec,
                      slot_base, bg, final_T, n_contrib, tile_max, dL_dpix, rows, row_flags);
 }
 
