@@ -360,50 +360,57 @@ def main():
         fwd_names = ["preprocess_fwd", "scan_block_sums", "duplicate_with_keys", "radix_sort", "identify_tile_ranges",
                      "render_fwd"]
         dominant = max((n for n in table), key=lambda n: table[n]["avg_ms"] * (1 if n in fwd_names else 0))
-        # HBM bytes and instruction counts per launch of the dominant kernel come from SEPARATE rocprofv3 --pmc passes
-        # of this same command (tools/refresh_profiles.py -> profiles/traffic.json).  The file carries the stamp of the
-        # kernel sources it was measured on: on a mismatch the fields are nulled rather than quoted stale.
-        traffic, issue, pmc_note = None, None, "no PMC measurement on file for this config"
+        # HBM bytes and instruction counts per launch come from SEPARATE rocprofv3 --pmc passes of this same command
+        # (tools/capture_profiles.sh + tools/refresh_profiles.py -> profiles/traffic.json).  The file carries the stamp
+        # of the kernel sources it was measured on: on a mismatch the fields are nulled rather than quoted stale.
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         try:
             tj = json.load(open(tfile))
-            stamp = tj.get("_stamp", {}).get(args.config, {})
-            entry = tj.get(args.config, {}).get(dominant, {})
-            if not entry:
-                pass
-            elif stamp.get("source_sha16") != source_stamp() or stamp.get("abi") != _lib.load().gsr_abi_version():
-                pmc_note = (f"profiles/traffic.json was measured at kernel sources {stamp.get('source_sha16')} / ABI "
-                            f"{stamp.get('abi')}, this run is {source_stamp()} / ABI {_lib.load().gsr_abi_version()}: "
-                            "PMC-derived fields nulled")
-            else:
-                traffic = entry.get("hbm_bytes_per_launch")
-                pmc_note = f"rocprofv3 --pmc passes at kernel sources {stamp.get('source_sha16')} ({stamp.get('label', '')})"
-                sq = entry.get("sq", {})
-                if sq.get("SQ_INSTS_VALU"):
-                    t_s = table[dominant]["avg_ms"] * 1e-3
-                    clk = 2.4e9
-                    # measured issue rates (tools/ubench/valu_rate.hip, profiles/r02/valu_rate.txt): a wave64 VALU
-                    # instruction occupies its SIMD for >= 2 cycles (v_exp_f32 8, v_cmp / v_cndmask 4), a SALU
-                    # instruction is issued at most every 4 cycles per SIMD; 1024 SIMDs
-                    valu_u = sq["SQ_INSTS_VALU"] * 2.0 / (1024 * clk * t_s)
-                    salu_u = sq.get("SQ_INSTS_SALU", 0) * 4.0 / (1024 * clk * t_s)
-                    lds_u = sq.get("SQ_INSTS_LDS", 0) * 4.0 / (256 * clk * t_s)
-                    util = {"valu_issue (2 cycles per wave64 instruction)": round(valu_u, 3),
-                            "salu_issue (4 cycles per instruction per SIMD)": round(salu_u, 3),
-                            "lds (4 cycles per ds_read_b128 per CU)": round(lds_u, 3)}
-                    if sq.get("SQ_ACTIVE_INST_VALU") and sq.get("SQ_BUSY_CYCLES"):
-                        util["valu_pipe_busy (SQ_ACTIVE_INST_VALU x 4 / SIMD cycles)"] = round(
-                            sq["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024 * clk * t_s), 3)
-                    issue = {"insts_per_launch": {k: int(v) for k, v in sq.items()}, "utilisation": util,
-                             "limiter": max(util, key=util.get),
-                             "note": "utilisations are lower bounds of the unit's busy share at the 2.4 GHz peak clock "
-                                     "(the chip clocks lower under VALU load) and cannot exceed 1"}
-        except Exception as ex:  # noqa: BLE001
-            pmc_note = f"profiles/traffic.json unreadable: {ex!r}"
-        roof = {"kernel": dominant, "bound": "hbm", "achieved": table[dominant]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": table[dominant]["frac_of_hbm_peak"], "traffic": traffic,
-                "avg_launch_ms": table[dominant]["avg_ms"], "algorithmic_bytes_per_launch": alg[dominant],
-                "issue": issue, "pmc_source": pmc_note}
+        except Exception:  # noqa: BLE001
+            tj = {}
+        stamp = tj.get("_stamp", {}).get(args.config, {})
+        abi_now = _lib.load().gsr_abi_version()
+        stamp_ok = bool(stamp) and stamp.get("source_sha16") == source_stamp() and stamp.get("abi") == abi_now
+        if not stamp:
+            pmc_note = "no PMC measurement on file for this config"
+        elif not stamp_ok:
+            pmc_note = (f"profiles/traffic.json was measured at kernel sources {stamp.get('source_sha16')} / ABI "
+                        f"{stamp.get('abi')}, this run is {source_stamp()} / ABI {abi_now}: PMC-derived fields nulled")
+        else:
+            pmc_note = f"rocprofv3 --pmc passes at kernel sources {stamp.get('source_sha16')} ({stamp.get('label', '')})"
+
+        def roofline_of(kernel):
+            """roofline object of one stage: algorithmic bytes / measured launch time against the HBM peak, plus (when a
+            PMC measurement of these very kernel sources is on file) the measured HBM bytes and the issue utilisations."""
+            t_s = table[kernel]["avg_ms"] * 1e-3
+            entry = tj.get(args.config, {}).get(kernel, {}) if stamp_ok else {}
+            issue = None
+            sq = entry.get("sq", {})
+            if sq.get("SQ_INSTS_VALU"):
+                clk = 2.4e9
+                # measured issue rates (tools/ubench/valu_rate.hip, profiles/r02/valu_rate.txt): a wave64 VALU instruction
+                # occupies its SIMD for >= 2.4 cycles (v_cmp / v_cndmask / v_min / v_max 4.7, v_exp / v_rcp 8.3), a SALU
+                # instruction is issued at most every ~4.7 cycles per SIMD; 1024 SIMDs, 256 LDS units
+                util = {"valu_issue_floor (2 cycles per wave64 instruction)": round(sq["SQ_INSTS_VALU"] * 2.0 / (1024 * clk * t_s), 3),
+                        "salu_issue (4 cycles per instruction per SIMD)": round(sq.get("SQ_INSTS_SALU", 0) * 4.0 / (1024 * clk * t_s), 3)}
+                if sq.get("SQ_LDS_IDX_ACTIVE"):
+                    util["lds_busy (SQ_LDS_IDX_ACTIVE / CU cycles)"] = round(sq["SQ_LDS_IDX_ACTIVE"] / (256 * clk * t_s), 3)
+                if sq.get("SQ_WAVE_CYCLES"):
+                    # share of the resident waves' lifetime spent parked on s_waitcnt / s_barrier vs waiting for an issue slot
+                    util["wave_time_parked (SQ_WAIT_ANY / SQ_WAVE_CYCLES)"] = round(sq.get("SQ_WAIT_ANY", 0) / sq["SQ_WAVE_CYCLES"], 3)
+                    util["wave_time_waiting_for_issue (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES)"] = round(sq.get("SQ_WAIT_INST_ANY", 0) / sq["SQ_WAVE_CYCLES"], 3)
+                units = {k: v for k, v in util.items() if k.startswith(("valu", "salu", "lds"))}
+                issue = {"insts_per_launch": {k: int(v) for k, v in sq.items()}, "utilisation": util,
+                         "limiter": max(units, key=units.get),
+                         "note": "utilisations are lower bounds of a unit's busy share at the 2.4 GHz peak clock (the chip "
+                                 "clocks at 1.9-2.3 GHz under VALU load; half- and quarter-rate instructions occupy the "
+                                 "VALU for 2-3.5x the floor) and cannot exceed 1"}
+            return {"kernel": kernel, "bound": "hbm", "achieved": table[kernel]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": table[kernel]["frac_of_hbm_peak"], "traffic": entry.get("hbm_bytes_per_launch"),
+                    "avg_launch_ms": table[kernel]["avg_ms"], "algorithmic_bytes_per_launch": alg[kernel],
+                    "issue": issue, "pmc_source": pmc_note}
+
+        roof = roofline_of(dominant)
         fwd_ms = t_fwd / K * 1e3
         train_ms = t_train / K * 1e3
         line = {
@@ -428,6 +435,9 @@ def main():
                        # up (the gloo numbers are diagnostics, not the north-star collective)
                        "valid": args.gaussians is None and not (rccl_failed and not share)},
             "roofline": roof,
+            # the two compositing kernels north_star singles out (VALU-issue-bound: DESIGN.md section 5)
+            "roofline_render_fwd": roofline_of("render_fwd") if "render_fwd" in table else None,
+            "roofline_render_bwd": roofline_of("render_bwd") if "render_bwd" in table else None,
             "roofline_by_kernel": table,
             "fwd_algorithmic_GB": round(sum(alg[n] for n in fwd_names) / 1e9, 3),
         }
