@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 9
+#define GSR_ABI_VERSION 10
 
 enum {
   GSR_OK = 0,
@@ -71,8 +71,8 @@ typedef struct GsrParams {
   const float* shs_rest;       /* NULL, or device [P,M-1,3] (16-byte aligned): then `shs` is [P,1,3] (f_dc) */
   int32_t act_flags;           /* GSR_ACT_*: inputs are RAW parameters, the activation (and its gradient) is applied here */
   int32_t binning_mode;        /* GSR_BINNING_*; same value in every call of a frame */
-  uint32_t* counts_pinned;     /* NULL, or HOST-PINNED, device-accessible uint32[2] (hipHostMalloc / torch pin_memory):
-                                  the scan kernel stores (num_rendered, num_visible) there and gsr_forward_preprocess
+  uint32_t* counts_pinned;     /* NULL, or HOST-PINNED, device-accessible uint32[4] (hipHostMalloc / torch pin_memory):
+                                  the scan kernel stores (num_rendered, num_visible, smallest and largest depth key) there and gsr_forward_preprocess
                                   waits on an event behind that kernel only, so the depth sort it has already
                                   enqueued keeps the GPU busy while the host sizes and launches stage 2 */
   int32_t forward_only;        /* 1: no gsr_backward will follow (inference): the compositing kernel does not track the

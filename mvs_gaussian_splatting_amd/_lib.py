@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class GsrParams(C.Structure):

@@ -90,10 +90,12 @@ __global__ __launch_bounds__(PRE_BLOCK) void compact_visible_kernel(int P, const
                                                                     const uint32_t* __restrict__ block_vis_offs,
                                                                     const uint32_t* __restrict__ block_offs,
                                                                     uint32_t* __restrict__ slot_base,
+                                                                    const uint32_t* __restrict__ depth_inv_min,
                                                                     uint32_t* __restrict__ dkey,
                                                                     uint32_t* __restrict__ didx) {
   __shared__ uint32_t wave_tot[PRE_BLOCK / WAVE];
   __shared__ uint32_t wave_tiles[PRE_BLOCK / WAVE];
+  const uint32_t min_bits = ~*depth_inv_min;      // smallest depth key of the frame: keys are sorted relative to it
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
   const int idx = blockIdx.x * PRE_BLOCK + tid;
   BinInfo bi{0u, 0u, 0.0f, 0u};
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void compact_visible_kernel(int P, const
     if (w < wid) { base += wave_tot[w]; tbase += wave_tiles[w]; }
   if (vis) {
     const uint32_t o = base + inc - 1u;
-    dkey[o] = __float_as_uint(bi.depth);
+    dkey[o] = __float_as_uint(bi.depth) - min_bits;     // order-preserving (positive floats, all >= the minimum)
     didx[o] = (uint32_t)idx;
   }
   // slot range of this Gaussian's per-instance gradient rows: index-major (any bijection works), coalesced write
@@ -621,11 +623,20 @@ bool launch_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b,
 }
 
 void launch_compact_visible(int P, const BinInfo* bin, const uint32_t* block_vis_offs, const uint32_t* block_offs,
-                            uint32_t* slot_base, uint32_t* dkey, uint32_t* didx, hipStream_t s) {
+                            uint32_t* slot_base, const uint32_t* depth_inv_min, uint32_t* dkey, uint32_t* didx, hipStream_t s) {
   const int nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
   if (nb > 0)
     hipLaunchKernelGGL(compact_visible_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, P, bin, block_vis_offs, block_offs, slot_base,
-                       dkey, didx);
+                       depth_inv_min, dkey, didx);
+}
+// one more pass on bits [shift, shift + nbits) of 32-bit keys (nbits <= 8): the top digit of the depth sort
+void launch_sort_extra_pass_u32(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, uint32_t n,
+                                const uint32_t* n_dev, int shift, int nbits, void* scratch, hipStream_t s) {
+  if (n == 0) return;
+  const SortLayout L(n);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + L.hist);
+  uint32_t* totals = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + L.totals);
+  sort_pass<uint32_t, 8>(kin, vin, kout, vout, n, n_dev, shift, nbits, L, hist, totals, s);
 }
 void launch_gather_tiles(uint32_t V, const uint32_t* didx, const BinInfo* bin, uint32_t* mask_sorted, uint2* rect_sorted,
                          uint32_t* block_sums2, hipStream_t s) {

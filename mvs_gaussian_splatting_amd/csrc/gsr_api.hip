@@ -171,7 +171,8 @@ int gsr_forward_preprocess(const GsrParams* p, void* geom_ws, int32_t* radii, vo
     StageTimer t(p, GSR_STAGE_PREPROCESS_FWD, s);
     launch_preprocess_fwd(*p, at<GeomRec>(geom_ws, L.rec), at<BinInfo>(geom_ws, L.bin),
                           at<uint32_t>(geom_ws, L.block_sums), at<uint32_t>(geom_ws, L.block_vis), radii,
-                          at<uint32_t>(geom_ws, L.total) + 2, at<uint32_t>(geom_ws, L.big_list), s);
+                          at<uint32_t>(geom_ws, L.total) + 2, at<uint32_t>(geom_ws, L.big_list),
+                          at<uint2>(geom_ws, L.block_range), s);
   }
   if (int rc = check(p, s, "preprocess_fwd")) return rc;
   uint32_t* total = at<uint32_t>(geom_ws, L.total);
@@ -179,9 +180,10 @@ int gsr_forward_preprocess(const GsrParams* p, void* geom_ws, int32_t* radii, vo
     StageTimer t(p, GSR_STAGE_SCAN, s);
     launch_scan_block_sums(at<uint32_t>(geom_ws, L.block_sums), at<uint32_t>(geom_ws, L.block_offs), total,
                            at<uint32_t>(geom_ws, L.block_vis), at<uint32_t>(geom_ws, L.block_vis_offs), total + 1,
-                           L.nblocks, s, p->counts_pinned);
+                           L.nblocks, s, p->counts_pinned, at<uint2>(geom_ws, L.block_range));
   }
   if (int rc = check(p, s, "scan_block_sums")) return rc;
+  uint32_t depth_min = 0, depth_max = 0;
   ScopedEvent counted;
   if (p->counts_pinned) {
     GSR_HIP(hipEventCreateWithFlags(&counted.e, hipEventDisableTiming));
@@ -193,10 +195,10 @@ int gsr_forward_preprocess(const GsrParams* p, void* geom_ws, int32_t* radii, vo
     StageTimer t(p, GSR_STAGE_SORT, s);
     launch_compact_visible(p->P, at<BinInfo>(geom_ws, L.bin), at<uint32_t>(geom_ws, L.block_vis_offs),
                            at<uint32_t>(geom_ws, L.block_offs),
-                           p->forward_only ? nullptr : at<uint32_t>(geom_ws, L.slot_base),
+                           p->forward_only ? nullptr : at<uint32_t>(geom_ws, L.slot_base), total + 4,
                            at<uint32_t>(geom_ws, L.dkey_a), at<uint32_t>(geom_ws, L.didx_a), s);
     launch_sort_pairs_u32(at<uint32_t>(geom_ws, L.dkey_a), at<uint32_t>(geom_ws, L.didx_a),
-                          at<uint32_t>(geom_ws, L.dkey_b), at<uint32_t>(geom_ws, L.didx_b), (uint32_t)p->P, 32,
+                          at<uint32_t>(geom_ws, L.dkey_b), at<uint32_t>(geom_ws, L.didx_b), (uint32_t)p->P, DEPTH_SORT_BITS,
                           at<char>(geom_ws, L.dsort), s, total + 1);
   }
   if (int rc = check(p, s, "depth_sort")) return rc;
@@ -205,12 +207,31 @@ int gsr_forward_preprocess(const GsrParams* p, void* geom_ws, int32_t* radii, vo
     if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize(counted)");
     *num_rendered = p->counts_pinned[0];
     *num_visible = p->counts_pinned[1];
+    depth_min = p->counts_pinned[2];
+    depth_max = p->counts_pinned[3];
   } else {
-    uint32_t host[2] = {0, 0};
+    uint32_t host[6] = {0, 0, 0, 0, 0, 0};
     GSR_HIP(hipMemcpyAsync(host, total, sizeof(host), hipMemcpyDeviceToHost, s));
     GSR_HIP(hipStreamSynchronize(s));
     *num_rendered = host[0];
     *num_visible = host[1];
+    depth_min = ~host[4];
+    depth_max = host[5];
+  }
+  if (p->binning_mode != GSR_BINNING_KEYS64 && *num_visible > 0 && depth_max >= depth_min &&
+      ((uint64_t)depth_max - depth_min) >> DEPTH_SORT_BITS) {
+    // more than 2^24 float32 steps of depth in one frame: sort the top digit too, then bring the indices back to where
+    // the three-pass result lives (stage 2 reads them from there)
+    StageTimer t(p, GSR_STAGE_SORT, s);
+    const bool in_b = (sort_passes(DEPTH_SORT_BITS) & 1) != 0;
+    uint32_t* k_in = at<uint32_t>(geom_ws, in_b ? L.dkey_b : L.dkey_a);
+    uint32_t* v_in = at<uint32_t>(geom_ws, in_b ? L.didx_b : L.didx_a);
+    uint32_t* k_out = at<uint32_t>(geom_ws, in_b ? L.dkey_a : L.dkey_b);
+    uint32_t* v_out = at<uint32_t>(geom_ws, in_b ? L.didx_a : L.didx_b);
+    launch_sort_extra_pass_u32(k_in, v_in, k_out, v_out, *num_visible, nullptr, DEPTH_SORT_BITS, 32 - DEPTH_SORT_BITS,
+                               at<char>(geom_ws, L.dsort), s);
+    GSR_HIP(hipMemcpyAsync(v_in, v_out, 4 * (size_t)*num_visible, hipMemcpyDeviceToDevice, s));
+    if (int rc = check(p, s, "depth_sort_top_digit")) return rc;
   }
   return 0;
 }
@@ -267,7 +288,7 @@ int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t b
       uint32_t* bsum2 = at<uint32_t>(bin_ws, B.bsum2);
       uint32_t* boffs2 = at<uint32_t>(bin_ws, B.boffs2);
       // depth-sorted Gaussian indices: produced by stage 1 (gsr_forward_preprocess) in the geometry workspace
-      const uint32_t* didx_sorted = at<uint32_t>(geom_ws, (sort_passes(32) & 1) ? L.didx_b : L.didx_a);
+      const uint32_t* didx_sorted = at<uint32_t>(geom_ws, (sort_passes(DEPTH_SORT_BITS) & 1) ? L.didx_b : L.didx_a);
       {
         StageTimer t(p, GSR_STAGE_DUPLICATE, s);   // instances emitted in depth order
         uint2* rect_sorted = at<uint2>(bin_ws, B.rect_sorted);

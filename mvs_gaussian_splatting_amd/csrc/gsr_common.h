@@ -88,7 +88,7 @@ constexpr int PRE_BLOCK = 256;      // Gaussians per preprocess / duplicate bloc
 
 // ---- workspace layouts (host + device agree through these helpers) -------------------------
 struct GeomLayout {
-  size_t rec, bin, offsets, slot_base, block_sums, block_offs, block_vis, block_vis_offs, total;
+  size_t rec, bin, offsets, slot_base, block_sums, block_offs, block_vis, block_vis_offs, block_range, total;
   size_t dkey_a, dkey_b, didx_a, didx_b, dsort, big_list, bytes;   // depth sort of the visible Gaussians (capacity P)
   int nblocks;
   __host__ __device__ explicit GeomLayout(int P) {
@@ -102,6 +102,7 @@ struct GeomLayout {
     block_offs = o; o = align_up(o + 4 * (size_t)(nblocks + 1), 256);
     block_vis = o;  o = align_up(o + 4 * (size_t)(nblocks + 1), 256);        // visible Gaussians per block
     block_vis_offs = o; o = align_up(o + 4 * (size_t)(nblocks + 1), 256);
+    block_range = o; o = align_up(o + 8 * (size_t)(nblocks + 1), 256);       // per block: max(~depth bits), max(depth bits)
     total = o;      o = align_up(o + 64, 256);                               // [0] = R (instances), [1] = V (visible),
                                                                              // [2] = entries of big_list
     dkey_a = o;     o = align_up(o + 4 * (size_t)P, 256);

@@ -8,14 +8,14 @@ namespace gsr {
 // preprocess.hip
 // big_count / big_list: Gaussians with more than ROWS_COOP instances are appended (big_count is zeroed here)
 void launch_preprocess_fwd(const GsrParams& p, GeomRec* rec, BinInfo* bin, uint32_t* block_sums, uint32_t* block_vis,
-                           int32_t* radii, uint32_t* big_count, uint32_t* big_list, hipStream_t s);
+                           int32_t* radii, uint32_t* big_count, uint32_t* big_list, uint2* block_range, hipStream_t s);
 // folds the gradient rows of every listed Gaussian into its first row (wave-cooperative, fixed order)
 void launch_sum_big_rows(const uint32_t* big_count, const uint32_t* big_list, const GeomRec* rec,
                          const uint32_t* slot_base, GradRow* rows, uint8_t* row_flags, hipStream_t s);
 // exclusive scans of up to two per-block arrays in one launch (block 0: a, block 1: b); total_x = grand total
 void launch_scan_block_sums(const uint32_t* sums_a, uint32_t* offs_a, uint32_t* total_a, const uint32_t* sums_b,
                             uint32_t* offs_b, uint32_t* total_b, int nb, hipStream_t s,
-                            uint32_t* host_mirror = nullptr);
+                            uint32_t* host_mirror = nullptr, const uint2* block_range = nullptr);
 void launch_preprocess_bwd(const GsrParams& p, const int32_t* radii, const GeomRec* rec, const uint32_t* slot_base,
                            const GradRow* rows,
                            const uint8_t* row_flags, const GsrGrads& g, hipStream_t s);
@@ -34,7 +34,14 @@ inline int sort_passes(int end_bit) { return (end_bit + RADIX_BITS - 1) / RADIX_
 void launch_identify_tile_ranges(uint32_t R, const uint64_t* keys, uint2* ranges, hipStream_t s);
 void launch_build_tile_order(int tiles, const uint2* ranges, uint32_t* order, hipStream_t s);
 void launch_compact_visible(int P, const BinInfo* bin, const uint32_t* block_vis_offs, const uint32_t* block_offs,
-                            uint32_t* slot_base, uint32_t* dkey, uint32_t* didx, hipStream_t s);
+                            uint32_t* slot_base, const uint32_t* depth_inv_min, uint32_t* dkey, uint32_t* didx, hipStream_t s);
+void launch_sort_extra_pass_u32(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, uint32_t n,
+                                const uint32_t* n_dev, int shift, int nbits, void* scratch, hipStream_t s);
+// The two-level binning sorts the visible Gaussians on (depth bits - smallest depth bits of the frame).  Three 8-bit
+// passes (24 bits: up to two binades of depth, e.g. 3 .. 12) are enqueued before the host knows the counts; a frame
+// that spans more gets the fourth 8-bit pass on bits 24..31 once the range has been read back with the counts.
+// (Three 9-bit passes were measured too: as slow as four 8-bit ones -- wider digits rank and scatter more slowly.)
+constexpr int DEPTH_SORT_BITS = 24;
 void launch_gather_tiles(uint32_t V, const uint32_t* didx, const BinInfo* bin, uint32_t* mask_sorted, uint2* rect_sorted,
                          uint32_t* block_sums2, hipStream_t s);
 void launch_emit_instances(uint32_t V, int grid_x, const uint32_t* didx, const uint32_t* mask_sorted,

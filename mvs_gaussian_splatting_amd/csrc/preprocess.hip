@@ -184,9 +184,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
                                                                    uint32_t* __restrict__ block_vis,
                                                                    int32_t* __restrict__ radii,
                                                                    uint32_t* __restrict__ big_count,
-                                                                   uint32_t* __restrict__ big_list) {
+                                                                   uint32_t* __restrict__ big_list,
+                                                                   uint2* __restrict__ block_range) {
   __shared__ uint32_t wave_sums[PRE_BLOCK / WAVE];
   __shared__ uint32_t wave_vis[PRE_BLOCK / WAVE];
+  __shared__ uint2 wave_range[PRE_BLOCK / WAVE];
   const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
   const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
   const int W = p.width, H = p.height;
@@ -381,17 +383,32 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
     bin[idx] = bi;
   }
 
+  // range of the depth keys of the Gaussians that enter the binning: the depth sort works on (bits - min), which
+  // needs 24 bits (three 8-bit passes) instead of 32 unless the frame spans more than 2^24 float32 steps of depth.
+  // Per block: max(~bits) (i.e. ~min: 0 when the block holds none) and max(bits); the scan kernel folds the blocks.
+  uint32_t dinv = tiles != 0u ? ~__float_as_uint(bi.depth) : 0u, dmax = tiles != 0u ? __float_as_uint(bi.depth) : 0u;
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) {
+    dinv = max(dinv, (uint32_t)__shfl_xor((int)dinv, d, WAVE));
+    dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, d, WAVE));
+  }
+
   // block total of tiles_touched -> first level of the hierarchical scan (§8 a5)
   const uint32_t ws = wave_reduce_add_u32(tiles);
   const uint32_t wv = (uint32_t)__popcll(__ballot(tiles != 0u));   // Gaussians that enter the binning
-  if (lane == 0) { wave_sums[wid] = ws; wave_vis[wid] = wv; }
+  if (lane == 0) { wave_sums[wid] = ws; wave_vis[wid] = wv; wave_range[wid] = make_uint2(dinv, dmax); }
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t s = 0, v = 0;
+    uint2 r = make_uint2(0u, 0u);
 #pragma unroll
-    for (int w = 0; w < PRE_BLOCK / WAVE; ++w) { s += wave_sums[w]; v += wave_vis[w]; }
+    for (int w = 0; w < PRE_BLOCK / WAVE; ++w) {
+      s += wave_sums[w]; v += wave_vis[w];
+      r.x = max(r.x, wave_range[w].x); r.y = max(r.y, wave_range[w].y);
+    }
     block_sums[blockIdx.x] = s;
     block_vis[blockIdx.x] = v;
+    block_range[blockIdx.x] = r;
   }
 }
 
@@ -404,9 +421,32 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t* _
                                                                 const uint32_t* __restrict__ sums_b,
                                                                 uint32_t* __restrict__ offs_b,
                                                                 uint32_t* __restrict__ total_b, int nb,
-                                                                uint32_t* __restrict__ host_mirror) {
+                                                                uint32_t* __restrict__ host_mirror,
+                                                                const uint2* __restrict__ block_range) {
   constexpr int PER = 32;
   __shared__ uint32_t wave_tot[1024 / WAVE];
+  __shared__ uint2 wave_range[1024 / WAVE];
+  if (blockIdx.x == 2) {      // third block (only launched with block_range): fold the per-block depth-key ranges
+    uint2 r = make_uint2(0u, 0u);
+    for (int b = threadIdx.x; b < nb; b += 1024) {
+      const uint2 q = block_range[b];
+      r.x = max(r.x, q.x); r.y = max(r.y, q.y);
+    }
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) {
+      r.x = max(r.x, (uint32_t)__shfl_xor((int)r.x, d, WAVE));
+      r.y = max(r.y, (uint32_t)__shfl_xor((int)r.y, d, WAVE));
+    }
+    if ((threadIdx.x & (WAVE - 1)) == 0) wave_range[threadIdx.x / WAVE] = r;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 1024 / WAVE; ++w) { r.x = max(r.x, wave_range[w].x); r.y = max(r.y, wave_range[w].y); }
+      total_a[4] = r.x;                 // total_a = [R, V, big, -, ~min, max]
+      total_a[5] = r.y;
+      if (host_mirror) { host_mirror[2] = ~r.x; host_mirror[3] = r.y; }
+    }
+    return;
+  }
   const uint32_t* __restrict__ block_sums = blockIdx.x == 0 ? sums_a : sums_b;
   uint32_t* __restrict__ block_offs = blockIdx.x == 0 ? offs_a : offs_b;
   uint32_t* __restrict__ total = blockIdx.x == 0 ? total_a : total_b;
@@ -840,17 +880,18 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(GsrParams p, 
 
 
 void launch_preprocess_fwd(const GsrParams& p, GeomRec* rec, BinInfo* bin, uint32_t* block_sums, uint32_t* block_vis,
-                           int32_t* radii, uint32_t* big_count, uint32_t* big_list, hipStream_t s) {
+                           int32_t* radii, uint32_t* big_count, uint32_t* big_list, uint2* block_range, hipStream_t s) {
   (void)hipMemsetAsync(big_count, 0, 4, s);
   const int nb = (p.P + PRE_BLOCK - 1) / PRE_BLOCK;
   if (nb > 0)
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, p, rec, bin, block_sums, block_vis, radii,
-                       big_count, big_list);
+                       big_count, big_list, block_range);
 }
 void launch_scan_block_sums(const uint32_t* sums_a, uint32_t* offs_a, uint32_t* total_a, const uint32_t* sums_b,
-                            uint32_t* offs_b, uint32_t* total_b, int nb, hipStream_t s, uint32_t* host_mirror) {
-  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(sums_b ? 2 : 1), dim3(1024), 0, s, sums_a, offs_a, total_a, sums_b,
-                     offs_b, total_b, nb, host_mirror);
+                            uint32_t* offs_b, uint32_t* total_b, int nb, hipStream_t s, uint32_t* host_mirror,
+                            const uint2* block_range) {
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(block_range ? 3 : (sums_b ? 2 : 1)), dim3(1024), 0, s, sums_a, offs_a, total_a,
+                     sums_b, offs_b, total_b, nb, host_mirror, block_range);
 }
 // One wave per listed Gaussian (grid-stride over the list, whose length lives on the device): flags are read 64 at
 // a time -- most are clear, the tiles behind an opaque surface never reach the instance -- flagged rows are summed in

@@ -701,3 +701,39 @@ def test_operator_rejects_misshaped_inputs(gpu_device):
     with pytest.raises(ValueError):
         col = dict(cov); del col["shs"]
         GaussianRasterizer(st)(cov3D_precomp=torch.zeros(64, 6, device=dev), colors_precomp=torch.zeros(64, 4, device=dev), **col)
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_depth_sort_of_a_frame_spanning_more_than_24_bits(gpu_device, pinned):
+    """The two-level binning sorts (depth bits - frame minimum) on 24 bits and adds the pass for the top digit only when
+    a frame spans more than 2^24 float32 steps of depth: lists must stay those of a full 32-bit (tile, depth) sort."""
+    from gpu_util import forward_with_state, product_settings
+    from mvs_gaussian_splatting_amd import render
+    from mvs_gaussian_splatting_amd.synthetic import PipelineParams
+    from oracle import rasterize_ref
+    model, cam, bg, _ = small_scene(P=2500, sh_degree=0, width=160, height=96)
+    g = torch.Generator().manual_seed(11)
+    z = torch.exp(torch.rand(2500, generator=g) * (math.log(2.0e6) - math.log(0.25)) + math.log(0.25))   # 0.25 .. 2e6: 23 binades
+    scale = z / model._xyz[:, 2]
+    model._xyz *= scale[:, None]                        # same screen positions, depths spread over 23 binades
+    model._scaling += torch.log(scale)[:, None]         # same screen-space footprints
+    st_o = make_settings(cam, bg, 0)
+    col, radii, aux = rasterize_ref(model.get_xyz, None, model.get_opacity, st_o, shs=model.get_features,
+                                    scales=model.get_scaling, rotations=model.get_rotation, want_aux=True, want_margin=True)
+    d = aux["pre"]["v_depth"][aux["pre"]["keep"]]
+    assert float(d.max() / d.min()) > 2.0 ** 17
+    if not pinned:      # raw C ABI without the pinned mirror: lists compared entry by entry
+        out = forward_with_state(gpu_device, product_settings(cam, bg, 0, gpu_device), model.get_xyz, model.get_opacity,
+                                 shs=model.get_features, scales=model.get_scaling, rotations=model.get_rotation)
+        # this cloud holds one Gaussian whose 3 sqrt(lambda) sits on an integer: its ceil() may differ by one between two
+        # float32 evaluations; tile rects, keys and lists are compared exactly all the same
+        assert int((out["radii"] != radii).sum()) <= 1 and int((out["radii"] - radii).abs().max()) <= 1
+        assert np.array_equal(out["keys"], aux["keys"]) and np.array_equal(out["point_list"], aux["point_list"])
+        img = out["color"]
+    else:               # the operator (pinned count mirror)
+        model.to(gpu_device); cam.to(gpu_device)
+        with torch.no_grad():
+            img = render(cam, model, PipelineParams(), bg.to(gpu_device))["render"].cpu()
+    robust = aux["margin"] > 1e-4
+    err = ((img - col).abs() / col.abs().clamp(min=1.0)).max(dim=0).values
+    assert float(err[robust].max()) <= 1e-5
