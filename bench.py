@@ -433,7 +433,8 @@ def main():
                        "rccl_ranks": rccl_ranks,
                        # invalid: a reduced problem, or ranks on distinct devices whose RCCL communicator did not come
                        # up (the gloo numbers are diagnostics, not the north-star collective)
-                       "valid": args.gaussians is None and not (rccl_failed and not share)},
+                       # ... and a rehearsal with several ranks on ONE card (GSR_BENCH_SHARE_GPU=1) is never a multi-GPU result
+                       "valid": args.gaussians is None and not rccl_failed and not (share and world > 1)},
             "roofline": roof,
             # the two compositing kernels north_star singles out (VALU-issue-bound: DESIGN.md section 5)
             "roofline_render_fwd": roofline_of("render_fwd") if "render_fwd" in table else None,

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256, 8) void render_fwd_kernel(int W, int H, int gr
 // ---- wave-wide sums ---------------------------------------------------------------------------
 template <int CTRL>
 __device__ inline float dpp_add(float v) {
-  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
   return v + __int_as_float(moved);
 }
 // every lane ends with the sum over its 16-lane row
