@@ -325,6 +325,11 @@ __global__ __launch_bounds__(256, 8) void render_fwd_kernel(int W, int H, int gr
       const uint32_t* c = reinterpret_cast<const uint32_t*>(&sCnt[w]);
       n_lane += (c[blk_r] >> (8 * blk_c)) & 0xffu;
     }
+    // a mini-block whose 16 pixels are all parked (saturated, or outside the image) has nothing left to composite
+    {
+      const unsigned long long alive = __builtin_amdgcn_ballot_w64(T > 0.0f);
+      if (((alive >> (16 * grp)) & 0xffffull) == 0ull) n_lane = 0;
+    }
     const uint32_t nmax = max(max((uint32_t)__builtin_amdgcn_readlane((int)n_lane, 0), (uint32_t)__builtin_amdgcn_readlane((int)n_lane, 16)),
                               max((uint32_t)__builtin_amdgcn_readlane((int)n_lane, 32), (uint32_t)__builtin_amdgcn_readlane((int)n_lane, 48)));
     // gathers of the next round (clamped indices: lanes past the end re-read the last instance and are masked by `have`)
@@ -451,6 +456,16 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, floa
   const uint2 range = ranges[tile];
   const uint32_t start = range.x;
   uint32_t hi = min(range.y - range.x, tile_max[tile]);   // instances past the last contributor get no gradient
+  // the same per 8x8 sub-block: the largest contributor index of its 64 pixels (a sub-block behind an opaque surface
+  // stops long before the rest of the tile)
+  uint32_t sub_last[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    uint32_t mx = last[k];
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, WAVE));
+    sub_last[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)mx);
+  }
 
   Staged st;
   st.q0 = st.q1 = st.q2 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -490,6 +505,9 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, floa
     sC[lane] = st.q2.x;
     __builtin_amdgcn_wave_barrier();
     const uint32_t cur_lo = lo;
+    // sub-blocks that still have a contributor in this round (1-based indices cur_lo + 1 .. hi); bit 4 = clamp flag
+    const uint32_t active = 16u | (sub_last[0] > cur_lo ? 1u : 0u) | (sub_last[1] > cur_lo ? 2u : 0u) |
+                            (sub_last[2] > cur_lo ? 4u : 0u) | (sub_last[3] > cur_lo ? 8u : 0u);
     hi = lo;
     lo = hi > BATCH ? hi - BATCH : 0u;
     {   // prefetch: record of the next (earlier) round, ids of the one after it
@@ -502,7 +520,8 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, floa
     while (nz) {
       const int j = 63 - __clzll((long long)nz);   // back to front
       nz &= ~(1ull << j);
-      const uint32_t mj = (uint32_t)__builtin_amdgcn_readlane((int)m, j);
+      const uint32_t mj = (uint32_t)__builtin_amdgcn_readlane((int)m, j) & active;
+      if ((mj & 15u) == 0u) continue;
       const float4 a = sA[j];
       const float4 b = sB[j];
       const float cb = sC[j];
