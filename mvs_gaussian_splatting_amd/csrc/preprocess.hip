@@ -428,9 +428,12 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t* _
   __shared__ uint2 wave_range[1024 / WAVE];
   if (blockIdx.x == 2) {      // third block (only launched with block_range): fold the per-block depth-key ranges
     uint2 r = make_uint2(0u, 0u);
-    for (int b = threadIdx.x; b < nb; b += 1024) {
-      const uint2 q = block_range[b];
-      r.x = max(r.x, q.x); r.y = max(r.y, q.y);
+    for (int b0 = threadIdx.x; b0 < nb; b0 += 8 * 1024) {      // eight independent loads in flight per lane
+      uint2 q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = b0 + u * 1024 < nb ? block_range[b0 + u * 1024] : make_uint2(0u, 0u);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { r.x = max(r.x, q[u].x); r.y = max(r.y, q[u].y); }
     }
 #pragma unroll
     for (int d = WAVE / 2; d > 0; d >>= 1) {
