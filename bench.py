@@ -357,6 +357,15 @@ def main():
             gbs = alg[name] / (avg_ms * 1e-3) / 1e9
             table[name] = {"avg_ms": round(avg_ms, 4), "launches": cnt, "frames": frames, "algorithmic_bytes": alg[name],
                            "achieved_GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+            if name == "radix_sort":
+                # SURVEY's model v1 prices upstream's 64-bit (tile, depth) sort of R pairs (152 R).  The default binning
+                # does not run that sort: it compacts the V visible Gaussians (16 P read, 8 V written), sorts them by
+                # 24-bit depth keys (3 passes x (4 V histogram read + 8 V read + 8 V written)) and partitions the R
+                # instances by tile id (2 passes x (4 R + 8 R + 8 R)).  Priced on the bytes it really moves:
+                moved = 16 * P + 8 * visible + 3 * 20 * visible + 2 * 20 * R
+                table[name]["bytes_moved_two_level"] = moved
+                table[name]["achieved_GBs_two_level"] = round(moved / (avg_ms * 1e-3) / 1e9, 1)
+                table[name]["frac_of_hbm_peak_two_level"] = round(moved / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         fwd_names = ["preprocess_fwd", "scan_block_sums", "duplicate_with_keys", "radix_sort", "identify_tile_ranges",
                      "render_fwd"]
         dominant = max((n for n in table), key=lambda n: table[n]["avg_ms"] * (1 if n in fwd_names else 0))
