@@ -220,7 +220,7 @@ __device__ __forceinline__ void walk_lists(const uint16_t* __restrict__ mylist, 
 }
 
 template <bool STATS, bool TRACK>
-__global__ __launch_bounds__(256, 8) void render_fwd_kernel(int W, int H, int grid_x, int num_tiles,
+__global__ __launch_bounds__(256, 8) void render_fwd_kernel(int W, int H, int grid_x, int cull_miniblocks,
                                                          const uint32_t* __restrict__ tile_order,
                                                          const uint2* __restrict__ ranges,
                                                          const uint32_t* __restrict__ point_list,
@@ -237,7 +237,6 @@ __global__ __launch_bounds__(256, 8) void render_fwd_kernel(int W, int H, int gr
   __shared__ __attribute__((aligned(16))) uint16_t sList[16][QLIST];
   __shared__ uint4 sCnt[4];             // per wave: counts of the 16 mini-blocks, one byte each
   __shared__ uint32_t sFlag[2][4];      // [0] any opacity > ALPHA_MAX in the round, [1] tile_max partials
-  (void)num_tiles;
   const int tid = threadIdx.x;
   const int lane = tid & (WAVE - 1);
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -289,7 +288,8 @@ __global__ __launch_bounds__(256, 8) void render_fwd_kernel(int W, int H, int gr
     sA[tid] = lr.A;
     sB[tid] = lr.B;
     sC[tid] = st.q2.x;
-    const uint32_t m16 = have ? miniblock_mask(st.q0.x - tx0, st.q0.y - ty0, st.q0.z, st.kk, st.isyy, st.q2.y, st.q2.z) : 0u;
+    uint32_t m16 = have ? miniblock_mask(st.q0.x - tx0, st.q0.y - ty0, st.q0.z, st.kk, st.isyy, st.q2.y, st.q2.z) : 0u;
+    if (!cull_miniblocks) m16 = have ? 0xffffu : 0u;      // debug (GSR_DEBUG_NO_MINIBLOCK_CULL): every pair is evaluated
     // ---- (b) wave-level ranks: four packed registers of four 8-bit counters --------------------------------------
     uint32_t own[4], incl[4];
 #pragma unroll
@@ -615,14 +615,18 @@ void launch_render_fwd(int W, int H, const uint2* ranges, const uint32_t* point_
                        const uint32_t* tile_order, hipStream_t s, unsigned long long* stats) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   const int nblk = gx * gy;       // one 256-lane workgroup per tile, longest list first
+  // debug switch for tests/test_gpu_miniblock_cull.py: with the cull off every staged instance enters all 16 lists;
+  // the image must not change by a bit (a dropped pair is a pair no pixel of which passes the alpha test)
+  const char* nc = getenv("GSR_DEBUG_NO_MINIBLOCK_CULL");
+  const int cull = (nc && nc[0] == '1') ? 0 : 1;
   if (stats)
-    hipLaunchKernelGGL((render_fwd_kernel<true, true>), dim3(nblk), dim3(256), 0, s, W, H, gx, gx * gy, tile_order, ranges,
+    hipLaunchKernelGGL((render_fwd_kernel<true, true>), dim3(nblk), dim3(256), 0, s, W, H, gx, cull, tile_order, ranges,
                        point_list, rec, bg, out_color, final_T, n_contrib, tile_max, stats);
   else if (final_T && n_contrib && tile_max)
-    hipLaunchKernelGGL((render_fwd_kernel<false, true>), dim3(nblk), dim3(256), 0, s, W, H, gx, gx * gy, tile_order, ranges,
+    hipLaunchKernelGGL((render_fwd_kernel<false, true>), dim3(nblk), dim3(256), 0, s, W, H, gx, cull, tile_order, ranges,
                        point_list, rec, bg, out_color, final_T, n_contrib, tile_max, stats);
   else      // forward only: no per-pixel state for a backward
-    hipLaunchKernelGGL((render_fwd_kernel<false, false>), dim3(nblk), dim3(256), 0, s, W, H, gx, gx * gy, tile_order, ranges,
+    hipLaunchKernelGGL((render_fwd_kernel<false, false>), dim3(nblk), dim3(256), 0, s, W, H, gx, cull, tile_order, ranges,
                        point_list, rec, bg, out_color, final_T, n_contrib, tile_max, stats);
 }
 void launch_render_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,

@@ -18,7 +18,7 @@ def product_settings(cam, bg, sh_degree, dev, scale_modifier=1.0, debug=False):
 
 
 def forward_with_state(dev, settings, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                       cov3D_precomp=None, binning_mode=None):
+                       cov3D_precomp=None, binning_mode=None, want_stats=False):
     """Forward through the C ABI keeping the workspaces; returns a dict of numpy/torch results."""
     lib = _lib.load()
     e = torch.empty(0, dtype=torch.float32, device=dev)
@@ -65,9 +65,19 @@ def forward_with_state(dev, settings, means3D, opacities, shs=None, colors_preco
         ranges = torch.empty(gx * gy, 2, dtype=torch.int32, device=dev)
         _lib.check(lib.gsr_debug_read_image(img.data_ptr(), W, H, final_T.data_ptr(), n_contrib.data_ptr(),
                                             ranges.data_ptr(), stream), "read_img")
+        stats = None
+        if want_stats and R > 0:      # work counters of the forward compositing kernel (re-runs it with counting on)
+            st8 = torch.zeros(8, dtype=torch.int64, device=dev)
+            scratch = torch.empty_like(color)
+            _lib.check(lib.gsr_debug_render_stats(C.byref(params), geom.data_ptr(), binning.data_ptr(), img.data_ptr(), R, V,
+                                                  scratch.data_ptr(), st8.data_ptr(), stream), "stats")
+            torch.cuda.synchronize(dev)
+            v = st8.cpu().tolist()
+            stats = {"instances": v[0], "staged": v[1], "pairs": v[2], "wave_evals": v[3]}
+            assert torch.equal(scratch, color)
         torch.cuda.synchronize(dev)
     del keep
-    return {"color": color.cpu(), "radii": radii.cpu(), "R": R, "V": V, "xy": xy.cpu(), "conic_opacity": con.cpu(),
+    return {"stats": stats, "color": color.cpu(), "radii": radii.cpu(), "R": R, "V": V, "xy": xy.cpu(), "conic_opacity": con.cpu(),
             "rgb": rgb.cpu(), "depth": depth.cpu(), "tiles": tiles.cpu().numpy().astype(np.int64),
             "offsets": offs.cpu().numpy().view(np.uint32), "rect": rect.cpu().numpy().astype(np.int64),
             "clamped": clamped.cpu().numpy(), "keys": keys[:R].cpu().numpy().view(np.uint64),

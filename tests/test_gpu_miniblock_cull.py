@@ -1,0 +1,75 @@
+"""The forward's 4x4 mini-block visit lists: an (instance, mini-block) pair is dropped only when
+every pixel of the mini-block fails alpha >= 1/255 in the evaluation's own float32 arithmetic.  With the cull switched
+off (GSR_DEBUG_NO_MINIBLOCK_CULL=1: every staged instance enters all 16 lists of its tile) the colour, the final
+transmittance and the last-contributor index of every pixel must be BIT-IDENTICAL -- on random clouds, on the
+rare-branch soup (screen-filling, sub-pixel, needle, guard-band, near-plane, opaque and transparent Gaussians) and on
+elongated splats at every orientation, which is what the row-span test (xc(dy) +- hw(dy), leftmost / rightmost rows) has
+to get right."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import small_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(dev, monkeypatch, model, cam, bg, deg, scale_modifier=1.0):
+    from gpu_util import forward_with_state, product_settings
+    st = product_settings(cam, bg, deg, dev, scale_modifier=scale_modifier)
+    outs = []
+    for off in ("0", "1"):
+        monkeypatch.setenv("GSR_DEBUG_NO_MINIBLOCK_CULL", off)
+        outs.append(forward_with_state(dev, st, model.get_xyz, model.get_opacity, shs=model.get_features,
+                                       scales=model.get_scaling, rotations=model.get_rotation, binning_mode=2, want_stats=True))
+    monkeypatch.delenv("GSR_DEBUG_NO_MINIBLOCK_CULL")
+    # the switch is live: without the cull every instance sits in all 16 lists of its tile (mini-blocks that lie outside
+    # the image or are saturated walk nothing, hence <=)
+    on, off = outs[0]["stats"], outs[1]["stats"]
+    assert on["instances"] == off["instances"] and 0.5 * 16 * off["instances"] < off["pairs"] <= 16 * off["instances"]
+    assert on["pairs"] < off["pairs"]            # (the rare-branch soup is mostly screen-filling splats: 9 % dropped)
+    return outs
+
+
+def _identical(a, b):
+    assert torch.equal(a["color"], b["color"])
+    assert torch.equal(a["final_T"], b["final_T"])
+    assert torch.equal(a["n_contrib"], b["n_contrib"])
+
+
+@pytest.mark.parametrize("seed,scale", [(0, 0.02), (1, 0.06), (2, 0.2), (3, 0.006)])
+def test_random_clouds(gpu_device, monkeypatch, seed, scale):
+    model, cam, bg, _ = small_scene(P=4000, sh_degree=1, width=243, height=139, scale=scale, seed=seed, view=seed)
+    a, b = _both(gpu_device, monkeypatch, model, cam, torch.tensor([0.2, 0.3, 0.1]), 1)
+    assert int((a["n_contrib"] > 0).sum()) > 1000
+    _identical(a, b)
+
+
+def test_rare_branch_soup(gpu_device, monkeypatch):
+    from test_gpu_parity import _stress_model
+    from mvs_gaussian_splatting_amd.synthetic import orbit_camera
+    model = _stress_model()
+    cam = orbit_camera(1, 8, 208, 136, 120.0, 120.0)
+    a, b = _both(gpu_device, monkeypatch, model, cam, torch.tensor([0.2, 0.4, 0.1]), 2, scale_modifier=1.3)
+    _identical(a, b)
+
+
+@pytest.mark.parametrize("ratio", [4.0, 20.0, 60.0])
+def test_needles_at_every_orientation(gpu_device, monkeypatch, ratio):
+    """Elongated splats rotated through all orientations, opacities from just above 1/255 to 1: the tilted ellipse's
+    row spans, its leftmost / rightmost rows and the inflated margins are what decides which mini-blocks are kept."""
+    model, cam, bg, _ = small_scene(P=3000, sh_degree=0, width=200, height=120, scale=0.05, seed=5)
+    g = torch.Generator().manual_seed(17)
+    P = 3000
+    long_axis = torch.exp(torch.rand(P, generator=g) * math.log(8.0) + math.log(0.03))
+    model._scaling[:, 0] = torch.log(long_axis)
+    model._scaling[:, 1] = torch.log(long_axis / ratio)
+    model._scaling[:, 2] = torch.log(long_axis / ratio)
+    ang = torch.rand(P, generator=g) * math.pi                       # rotation about the view axis: every orientation
+    model._rotation[:] = torch.stack([torch.cos(ang / 2), torch.zeros(P), torch.zeros(P), torch.sin(ang / 2)], dim=1)
+    model._opacity[:] = torch.logit(torch.exp(torch.rand(P, 1, generator=g) * (math.log(0.999) - math.log(0.0045)) + math.log(0.0045)))
+    a, b = _both(gpu_device, monkeypatch, model, cam, torch.tensor([0.0, 0.0, 0.0]), 0)
+    assert int((a["n_contrib"] > 0).sum()) > 5000
+    _identical(a, b)

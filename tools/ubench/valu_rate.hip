@@ -11,15 +11,18 @@
 #define REP16(x) REP4(REP4(x))
 
 enum { FMA8 = 0, PKFMA4, CHAIN, EXP8, CMPSEL, SALU, LDSB128, VISIT, FMA_SALU, CMP32, CMP64, SEL32, SEL64, MINMAX, FMA_HALF,
-       EXP_HALF, READLANE, SAVEEXEC, VMOV, LDS_FMA, CMPX, NMODES };
+       EXP_HALF, READLANE, SAVEEXEC, VMOV, LDS_FMA, CMPX, DPPADD, DPPROW, PERM32, PERM16, RCP, RDFIRST, MED3, BPERM, NMODES };
 static const char* names[NMODES] = {"v_fma_f32 x16 (indep)", "v_pk_fma_f32 x16 (indep)", "v_fma_f32 chain x16",
                                     "v_exp_f32 x16 (indep)", "v_cmp+v_cndmask x8 pairs", "s_add_u32 x16 (SALU)",
                                     "ds_read_b128 broadcast x16", "visit mix (12 valu+1 exp)", "8 fma + 8 salu interleaved",
                                     "v_cmp_lt_f32 vcc x16", "v_cmp_lt_f32 -> sgpr pair x16", "v_cndmask_b32 vcc x16",
                                     "v_cndmask_b32 sgpr mask x16", "v_min/v_max x16", "v_fma_f32 x16, EXEC = low 32 lanes",
                                     "v_exp_f32 x16, EXEC = low 32 lanes", "v_readlane_b32 x16", "s_and_saveexec + s_or x8 pairs",
-                                    "v_mov_b32 x16", "4 ds_read_b128 bcast + 12 fma", "v_cmpx_lt + restore x8 pairs"};
-static const int insts[NMODES] = {16, 16, 16, 16, 16, 16, 16, 13, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16};
+                                    "v_mov_b32 x16", "4 ds_read_b128 bcast + 12 fma", "v_cmpx_lt + restore x8 pairs",
+                                    "v_add_f32_dpp quad_perm x16", "v_add_f32_dpp row_mirror / row_ror x16", "v_permlane32_swap x16",
+                                    "v_permlane16_swap x16", "v_rcp_f32 x16", "v_readfirstlane_b32 x16", "v_med3_f32 x16",
+                                    "ds_bpermute_b32 x16"};
+static const int insts[NMODES] = {16, 16, 16, 16, 16, 16, 16, 13, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16};
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float* out, unsigned long long* clk, int iters, float a, float b) {
@@ -183,6 +186,54 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* clk, in
       asm volatile(REP4("v_cmpx_lt_f32 vcc, %0, %1\n s_mov_b64 exec, -1\n v_cmpx_lt_f32 vcc, %0, %1\n s_mov_b64 exec, -1\n"
                         "v_cmpx_lt_f32 vcc, %0, %1\n s_mov_b64 exec, -1\n v_cmpx_lt_f32 vcc, %0, %1\n s_mov_b64 exec, -1\n")
                    : : "v"(a), "v"(b) : "vcc");
+    } else if (MODE == DPPADD) {
+      asm volatile(
+          "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          "v_add_f32_dpp %6, %6, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %7, %7, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          "v_add_f32_dpp %6, %6, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %7, %7, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+    } else if (MODE == DPPROW) {
+      asm volatile(
+          "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          "v_add_f32_dpp %4, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          "v_add_f32_dpp %6, %6, %6 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %7, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          "v_add_f32_dpp %4, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          "v_add_f32_dpp %6, %6, %6 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %7, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+          : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+    } else if (MODE == PERM32) {
+      asm volatile(REP4("v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n")
+                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+    } else if (MODE == PERM16) {
+      asm volatile(REP4("v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %4, %5\n v_permlane16_swap_b32 %6, %7\n")
+                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+    } else if (MODE == RCP) {
+      asm volatile(
+          "v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n"
+          "v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n"
+          : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+    } else if (MODE == RDFIRST) {
+      asm volatile(REP4("v_readfirstlane_b32 s20, %0\n v_readfirstlane_b32 s21, %1\n v_readfirstlane_b32 s22, %2\n v_readfirstlane_b32 s23, %3\n")
+                   : : "v"(x0), "v"(x1), "v"(x2), "v"(x3) : "s20", "s21", "s22", "s23");
+    } else if (MODE == MED3) {
+      asm volatile(
+          "v_med3_f32 %0, %0, %8, %9\n v_med3_f32 %1, %1, %8, %9\n v_med3_f32 %2, %2, %8, %9\n v_med3_f32 %3, %3, %8, %9\n"
+          "v_med3_f32 %4, %4, %8, %9\n v_med3_f32 %5, %5, %8, %9\n v_med3_f32 %6, %6, %8, %9\n v_med3_f32 %7, %7, %8, %9\n"
+          "v_med3_f32 %0, %0, %8, %9\n v_med3_f32 %1, %1, %8, %9\n v_med3_f32 %2, %2, %8, %9\n v_med3_f32 %3, %3, %8, %9\n"
+          "v_med3_f32 %4, %4, %8, %9\n v_med3_f32 %5, %5, %8, %9\n v_med3_f32 %6, %6, %8, %9\n v_med3_f32 %7, %7, %8, %9\n"
+          : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
+    } else if (MODE == BPERM) {
+      const uint32_t addr = (uint32_t)(((threadIdx.x + 1) & 63) * 4);
+      asm volatile(
+          REP4("ds_bpermute_b32 %0, %4, %0\n ds_bpermute_b32 %1, %4, %1\n ds_bpermute_b32 %2, %4, %2\n ds_bpermute_b32 %3, %4, %3\n s_waitcnt lgkmcnt(0)\n")
+          : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(addr));
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -215,6 +266,7 @@ int main() {
     run<FMA8>(w); run<PKFMA4>(w); run<CHAIN>(w); run<EXP8>(w); run<CMPSEL>(w); run<SALU>(w); run<LDSB128>(w); run<VISIT>(w);
     run<FMA_SALU>(w); run<CMP32>(w); run<CMP64>(w); run<SEL32>(w); run<SEL64>(w); run<MINMAX>(w); run<FMA_HALF>(w);
     run<EXP_HALF>(w); run<READLANE>(w); run<SAVEEXEC>(w); run<VMOV>(w); run<LDS_FMA>(w); run<CMPX>(w);
+    run<DPPADD>(w); run<DPPROW>(w); run<PERM32>(w); run<PERM16>(w); run<RCP>(w); run<RDFIRST>(w); run<MED3>(w); run<BPERM>(w);
   }
   return 0;
 }
