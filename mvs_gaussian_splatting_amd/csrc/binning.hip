@@ -91,8 +91,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void compact_visible_kernel(int P, const
                                                                     const uint32_t* __restrict__ block_offs,
                                                                     uint32_t* __restrict__ slot_base,
                                                                     const uint32_t* __restrict__ depth_inv_min,
+                                                                    int grid_x,
                                                                     uint32_t* __restrict__ dkey,
-                                                                    uint32_t* __restrict__ didx) {
+                                                                    uint2* __restrict__ dval) {
   __shared__ uint32_t wave_tot[PRE_BLOCK / WAVE];
   __shared__ uint32_t wave_tiles[PRE_BLOCK / WAVE];
   const uint32_t min_bits = ~*depth_inv_min;      // smallest depth key of the frame: keys are sorted relative to it
@@ -114,26 +115,30 @@ __global__ __launch_bounds__(PRE_BLOCK) void compact_visible_kernel(int P, const
   if (vis) {
     const uint32_t o = base + inc - 1u;
     dkey[o] = __float_as_uint(bi.depth) - min_bits;     // order-preserving (positive floats, all >= the minimum)
-    didx[o] = (uint32_t)idx;
+    // the payload of the depth sort: the index and, for the common small rect, everything the instance emission needs
+    // (so that no random gather of BinInfo follows the sort)
+    dval[o] = make_uint2((uint32_t)idx, pack_rect(bi.rect_min, bi.rect_wh, bi.mask, (uint32_t)grid_x));
   }
   // slot range of this Gaussian's per-instance gradient rows: index-major (any bijection works), coalesced write
   if (slot_base && idx < P) slot_base[idx] = tbase + tinc - tiles;     // NULL: forward only
 }
 
-__global__ __launch_bounds__(PRE_BLOCK) void gather_tiles_kernel(uint32_t V, const uint32_t* __restrict__ didx,
-                                                                 const BinInfo* __restrict__ bin,
-                                                                 uint32_t* __restrict__ mask_sorted,
-                                                                 uint2* __restrict__ rect_sorted,
-                                                                 uint32_t* __restrict__ block_sums2) {
+// tiles of a depth-sorted Gaussian: from the packed rect that travelled with it, or (rare: rects wider than four tiles
+// or of more than 16) from its BinInfo
+__device__ inline uint32_t sorted_tiles(uint2 v, const BinInfo* __restrict__ bin) {
+  if (v.y & PACK_FALLBACK) {
+    const BinInfo bi = bin[v.x];
+    return bin_count(bi.rect_wh, bi.mask);
+  }
+  return (uint32_t)__popc(v.y >> PACK_MASK_SHIFT);
+}
+
+__global__ __launch_bounds__(PRE_BLOCK) void count_tiles_kernel(uint32_t V, const uint2* __restrict__ dval,
+                                                                const BinInfo* __restrict__ bin,
+                                                                uint32_t* __restrict__ block_sums2) {
   __shared__ uint32_t wave_tot[PRE_BLOCK / WAVE];
   const uint32_t i = blockIdx.x * PRE_BLOCK + threadIdx.x;
-  uint32_t t = 0;
-  if (i < V) {
-    const BinInfo bi = bin[didx[i]];          // the one random gather of the binning stage
-    t = bin_count(bi.rect_wh, bi.mask);
-    mask_sorted[i] = bi.mask;
-    rect_sorted[i] = make_uint2(bi.rect_min, bi.rect_wh);
-  }
+  const uint32_t t = i < V ? sorted_tiles(dval[i], bin) : 0u;
   const uint32_t ws = wave_reduce_add_u32(t);
   if ((threadIdx.x & (WAVE - 1)) == 0) wave_tot[threadIdx.x / WAVE] = ws;
   __syncthreads();
@@ -150,9 +155,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void gather_tiles_kernel(uint32_t V, con
 // (LDS) and derives the tile from the slot's rank inside the rect -- fully coalesced stores, no divergence on
 // the splat size (a per-Gaussian loop here ran at 0.5 TB/s).
 __global__ __launch_bounds__(PRE_BLOCK) void emit_instances_kernel(uint32_t V, int grid_x,
-                                                                   const uint32_t* __restrict__ didx,
-                                                                   const uint32_t* __restrict__ mask_sorted,
-                                                                   const uint2* __restrict__ rect_sorted,
+                                                                   const uint2* __restrict__ dval,
+                                                                   const BinInfo* __restrict__ bin,
                                                                    const uint32_t* __restrict__ block_offs2,
                                                                    uint32_t* __restrict__ inst_tile,
                                                                    uint32_t* __restrict__ inst_g) {
@@ -167,9 +171,15 @@ __global__ __launch_bounds__(PRE_BLOCK) void emit_instances_kernel(uint32_t V, i
   uint32_t g = 0, tiles = 0, mask = 0;
   uint2 rr = make_uint2(0u, 0u);
   if (i < V) {
-    g = didx[i];
-    mask = mask_sorted[i];
-    rr = rect_sorted[i];
+    const uint2 v = dval[i];
+    g = v.x;
+    if (v.y & PACK_FALLBACK) {
+      const BinInfo bi = bin[g];
+      mask = bi.mask;
+      rr = make_uint2(bi.rect_min, bi.rect_wh);
+    } else {
+      unpack_rect(v.y, (uint32_t)grid_x, rr.x, rr.y, mask);
+    }
     tiles = bin_count(rr.y, mask);
   }
   const uint32_t inc = wave_incl_scan_u32(tiles);
@@ -311,16 +321,18 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(uint32_t* __restrict
   if (tid == 0) totals[blockIdx.x] = carry;
 }
 
-template <typename KeyT, int BITS, int ITEMS>
+template <typename KeyT, typename ValT, int BITS, int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
-    const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, KeyT* __restrict__ keys_out,
-    uint32_t* __restrict__ vals_out, uint32_t n, const uint32_t* __restrict__ n_dev, int shift, uint32_t mask,
+    const KeyT* __restrict__ keys_in, const ValT* __restrict__ vals_in, KeyT* __restrict__ keys_out,
+    ValT* __restrict__ vals_out, uint32_t n, const uint32_t* __restrict__ n_dev, int shift, uint32_t mask,
     uint32_t nblocks, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals) {
   constexpr int RADIX = 1 << BITS;
   constexpr int NW = SORT_THREADS / WAVE;
   if (n_dev) n = *n_dev;
   if (blockIdx.x * (SORT_THREADS * ITEMS) >= n) return;   // block beyond the device-side count (uniform: no barrier crossed)
-  __shared__ KeyT xbuf[(SORT_THREADS * ITEMS)];            // exchange buffer: keys first, then reused for the values
+  using WideT = typename std::conditional<(sizeof(ValT) > sizeof(KeyT)), ValT, KeyT>::type;
+  __shared__ WideT xbuf_w[(SORT_THREADS * ITEMS)];         // exchange buffer: keys first, then reused for the values
+  KeyT* xbuf = reinterpret_cast<KeyT*>(xbuf_w);
   __shared__ uint32_t wave_hist[NW][RADIX];   // per-wave digit counts, then exclusive wave prefixes
   __shared__ uint32_t digit_start[RADIX];     // first local slot of every digit
   __shared__ uint32_t global_base[RADIX];     // global position of the block's first item of the digit
@@ -337,7 +349,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
   __syncthreads();
 
   KeyT k[ITEMS];
-  uint32_t v[ITEMS];
+  ValT v[ITEMS];
   uint32_t rank[ITEMS];
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {
@@ -454,7 +466,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     }
   }
   __syncthreads();
-  uint32_t* xv = reinterpret_cast<uint32_t*>(xbuf);
+  ValT* xv = reinterpret_cast<ValT*>(xbuf_w);
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {
     const uint32_t g = wbase + i * WAVE + lane;
@@ -563,8 +575,8 @@ void launch_duplicate_with_keys(int P, int grid_x, const BinInfo* bin, const uin
                        point_offsets, keys, vals);
 }
 
-template <typename KeyT, int BITS>
-static void sort_pass(const KeyT* kin, const uint32_t* vin, KeyT* kout, uint32_t* vout, uint32_t n, const uint32_t* n_dev,
+template <typename KeyT, typename ValT, int BITS>
+static void sort_pass(const KeyT* kin, const ValT* vin, KeyT* kout, ValT* vout, uint32_t n, const uint32_t* n_dev,
                       int shift, int nbits, const SortLayout& L, uint32_t* hist, uint32_t* totals, hipStream_t s) {
   const uint32_t mask = (1u << nbits) - 1u;      // nbits <= BITS: digits above the mask do not occur
   // (8192-item tiles for 32-bit keys were measured: no gain once the digits are <= 8 bits wide)
@@ -574,7 +586,7 @@ static void sort_pass(const KeyT* kin, const uint32_t* vin, KeyT* kout, uint32_t
   hipLaunchKernelGGL((radix_hist_kernel<KeyT, BITS, ITEMS>), dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, n, n_dev, shift,
                      mask, nblocks, hist);
   hipLaunchKernelGGL(radix_rowscan_kernel, dim3(1 << BITS), dim3(256), 0, s, hist, nblocks, totals);
-  hipLaunchKernelGGL((radix_scatter_kernel<KeyT, BITS, ITEMS>), dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, vin, kout,
+  hipLaunchKernelGGL((radix_scatter_kernel<KeyT, ValT, BITS, ITEMS>), dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, vin, kout,
                      vout, n, n_dev, shift, mask, nblocks, hist, totals);
 }
 
@@ -590,8 +602,8 @@ int sort_pass_plan(int end_bit, int widths[8]) {
 }
 
 // n = element count, or the capacity when n_dev (device-side count) is given
-template <typename KeyT>
-static bool sort_pairs_impl(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t* vals_b, uint32_t n, int end_bit,
+template <typename KeyT, typename ValT>
+static bool sort_pairs_impl(KeyT* keys_a, ValT* vals_a, KeyT* keys_b, ValT* vals_b, uint32_t n, int end_bit,
                             void* scratch, hipStream_t s, const uint32_t* n_dev = nullptr) {
   if (n == 0 || end_bit <= 0) return false;
   const SortLayout L(n);
@@ -599,59 +611,60 @@ static bool sort_pairs_impl(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32
   uint32_t* totals = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + L.totals);
   int widths[8];
   const int passes = sort_pass_plan(end_bit, widths);
-  KeyT* kin = keys_a; uint32_t* vin = vals_a; KeyT* kout = keys_b; uint32_t* vout = vals_b;
+  KeyT* kin = keys_a; ValT* vin = vals_a; KeyT* kout = keys_b; ValT* vout = vals_b;
   int shift = 0;
   for (int pass = 0; pass < passes; ++pass) {
     const int w = widths[pass];
-    if (w <= 6)      sort_pass<KeyT, 6>(kin, vin, kout, vout, n, n_dev, shift, w, L, hist, totals, s);
-    else if (w == 7) sort_pass<KeyT, 7>(kin, vin, kout, vout, n, n_dev, shift, w, L, hist, totals, s);
-    else if (w == 8) sort_pass<KeyT, 8>(kin, vin, kout, vout, n, n_dev, shift, w, L, hist, totals, s);
-    else             sort_pass<KeyT, 9>(kin, vin, kout, vout, n, n_dev, shift, w, L, hist, totals, s);
+    if (w <= 6)      sort_pass<KeyT, ValT, 6>(kin, vin, kout, vout, n, n_dev, shift, w, L, hist, totals, s);
+    else if (w == 7) sort_pass<KeyT, ValT, 7>(kin, vin, kout, vout, n, n_dev, shift, w, L, hist, totals, s);
+    else if (w == 8) sort_pass<KeyT, ValT, 8>(kin, vin, kout, vout, n, n_dev, shift, w, L, hist, totals, s);
+    else             sort_pass<KeyT, ValT, 9>(kin, vin, kout, vout, n, n_dev, shift, w, L, hist, totals, s);
     shift += w;
     KeyT* tk = kin; kin = kout; kout = tk;
-    uint32_t* tv = vin; vin = vout; vout = tv;
+    ValT* tv = vin; vin = vout; vout = tv;
   }
   return (passes & 1) != 0;
 }
 bool launch_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, uint32_t n,
                        int end_bit, void* scratch, hipStream_t s) {
-  return sort_pairs_impl<uint64_t>(keys_a, vals_a, keys_b, vals_b, n, end_bit, scratch, s);
+  return sort_pairs_impl<uint64_t, uint32_t>(keys_a, vals_a, keys_b, vals_b, n, end_bit, scratch, s);
 }
 bool launch_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n,
                            int end_bit, void* scratch, hipStream_t s, const uint32_t* n_dev) {
-  return sort_pairs_impl<uint32_t>(keys_a, vals_a, keys_b, vals_b, n, end_bit, scratch, s, n_dev);
+  return sort_pairs_impl<uint32_t, uint32_t>(keys_a, vals_a, keys_b, vals_b, n, end_bit, scratch, s, n_dev);
+}
+bool launch_sort_pairs_u32_v64(uint32_t* keys_a, uint2* vals_a, uint32_t* keys_b, uint2* vals_b, uint32_t n,
+                               int end_bit, void* scratch, hipStream_t s, const uint32_t* n_dev) {
+  return sort_pairs_impl<uint32_t, uint2>(keys_a, vals_a, keys_b, vals_b, n, end_bit, scratch, s, n_dev);
 }
 
 void launch_compact_visible(int P, const BinInfo* bin, const uint32_t* block_vis_offs, const uint32_t* block_offs,
-                            uint32_t* slot_base, const uint32_t* depth_inv_min, uint32_t* dkey, uint32_t* didx, hipStream_t s) {
+                            uint32_t* slot_base, const uint32_t* depth_inv_min, int grid_x, uint32_t* dkey, uint2* dval,
+                            hipStream_t s) {
   const int nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
   if (nb > 0)
     hipLaunchKernelGGL(compact_visible_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, P, bin, block_vis_offs, block_offs, slot_base,
-                       depth_inv_min, dkey, didx);
+                       depth_inv_min, grid_x, dkey, dval);
 }
 // one more pass on bits [shift, shift + nbits) of 32-bit keys (nbits <= 8): the top digit of the depth sort
-void launch_sort_extra_pass_u32(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, uint32_t n,
+void launch_sort_extra_pass_u32(const uint32_t* kin, const uint2* vin, uint32_t* kout, uint2* vout, uint32_t n,
                                 const uint32_t* n_dev, int shift, int nbits, void* scratch, hipStream_t s) {
   if (n == 0) return;
   const SortLayout L(n);
   uint32_t* hist = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + L.hist);
   uint32_t* totals = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + L.totals);
-  sort_pass<uint32_t, 8>(kin, vin, kout, vout, n, n_dev, shift, nbits, L, hist, totals, s);
+  sort_pass<uint32_t, uint2, 8>(kin, vin, kout, vout, n, n_dev, shift, nbits, L, hist, totals, s);
 }
-void launch_gather_tiles(uint32_t V, const uint32_t* didx, const BinInfo* bin, uint32_t* mask_sorted, uint2* rect_sorted,
-                         uint32_t* block_sums2, hipStream_t s) {
+void launch_count_tiles(uint32_t V, const uint2* dval, const BinInfo* bin, uint32_t* block_sums2, hipStream_t s) {
+  const uint32_t nb = (V + PRE_BLOCK - 1) / PRE_BLOCK;
+  if (nb) hipLaunchKernelGGL(count_tiles_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, V, dval, bin, block_sums2);
+}
+void launch_emit_instances(uint32_t V, int grid_x, const uint2* dval, const BinInfo* bin, const uint32_t* block_offs2,
+                           uint32_t* inst_tile, uint32_t* inst_g, hipStream_t s) {
   const uint32_t nb = (V + PRE_BLOCK - 1) / PRE_BLOCK;
   if (nb)
-    hipLaunchKernelGGL(gather_tiles_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, V, didx, bin, mask_sorted, rect_sorted,
-                       block_sums2);
-}
-void launch_emit_instances(uint32_t V, int grid_x, const uint32_t* didx, const uint32_t* mask_sorted,
-                           const uint2* rect_sorted, const uint32_t* block_offs2, uint32_t* inst_tile, uint32_t* inst_g,
-                           hipStream_t s) {
-  const uint32_t nb = (V + PRE_BLOCK - 1) / PRE_BLOCK;
-  if (nb)
-    hipLaunchKernelGGL(emit_instances_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, V, grid_x, didx, mask_sorted, rect_sorted,
-                       block_offs2, inst_tile, inst_g);
+    hipLaunchKernelGGL(emit_instances_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, V, grid_x, dval, bin, block_offs2, inst_tile,
+                       inst_g);
 }
 void launch_reconstruct_keys(uint32_t R, const uint32_t* tile_sorted, const uint32_t* point_list, const BinInfo* bin,
                              uint64_t* keys, hipStream_t s) {

@@ -196,10 +196,10 @@ int gsr_forward_preprocess(const GsrParams* p, void* geom_ws, int32_t* radii, vo
     launch_compact_visible(p->P, at<BinInfo>(geom_ws, L.bin), at<uint32_t>(geom_ws, L.block_vis_offs),
                            at<uint32_t>(geom_ws, L.block_offs),
                            p->forward_only ? nullptr : at<uint32_t>(geom_ws, L.slot_base), total + 4,
-                           at<uint32_t>(geom_ws, L.dkey_a), at<uint32_t>(geom_ws, L.didx_a), s);
-    launch_sort_pairs_u32(at<uint32_t>(geom_ws, L.dkey_a), at<uint32_t>(geom_ws, L.didx_a),
-                          at<uint32_t>(geom_ws, L.dkey_b), at<uint32_t>(geom_ws, L.didx_b), (uint32_t)p->P, DEPTH_SORT_BITS,
-                          at<char>(geom_ws, L.dsort), s, total + 1);
+                           (p->width + TILE - 1) / TILE, at<uint32_t>(geom_ws, L.dkey_a), at<uint2>(geom_ws, L.didx_a), s);
+    launch_sort_pairs_u32_v64(at<uint32_t>(geom_ws, L.dkey_a), at<uint2>(geom_ws, L.didx_a),
+                              at<uint32_t>(geom_ws, L.dkey_b), at<uint2>(geom_ws, L.didx_b), (uint32_t)p->P,
+                              DEPTH_SORT_BITS, at<char>(geom_ws, L.dsort), s, total + 1);
   }
   if (int rc = check(p, s, "depth_sort")) return rc;
   if (counted.e) {
@@ -225,12 +225,12 @@ int gsr_forward_preprocess(const GsrParams* p, void* geom_ws, int32_t* radii, vo
     StageTimer t(p, GSR_STAGE_SORT, s);
     const bool in_b = (sort_passes(DEPTH_SORT_BITS) & 1) != 0;
     uint32_t* k_in = at<uint32_t>(geom_ws, in_b ? L.dkey_b : L.dkey_a);
-    uint32_t* v_in = at<uint32_t>(geom_ws, in_b ? L.didx_b : L.didx_a);
+    uint2* v_in = at<uint2>(geom_ws, in_b ? L.didx_b : L.didx_a);
     uint32_t* k_out = at<uint32_t>(geom_ws, in_b ? L.dkey_a : L.dkey_b);
-    uint32_t* v_out = at<uint32_t>(geom_ws, in_b ? L.didx_a : L.didx_b);
+    uint2* v_out = at<uint2>(geom_ws, in_b ? L.didx_a : L.didx_b);
     launch_sort_extra_pass_u32(k_in, v_in, k_out, v_out, *num_visible, nullptr, DEPTH_SORT_BITS, 32 - DEPTH_SORT_BITS,
                                at<char>(geom_ws, L.dsort), s);
-    GSR_HIP(hipMemcpyAsync(v_in, v_out, 4 * (size_t)*num_visible, hipMemcpyDeviceToDevice, s));
+    GSR_HIP(hipMemcpyAsync(v_in, v_out, 8 * (size_t)*num_visible, hipMemcpyDeviceToDevice, s));
     if (int rc = check(p, s, "depth_sort_top_digit")) return rc;
   }
   return 0;
@@ -284,17 +284,15 @@ int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t b
       uint32_t* itb = at<uint32_t>(bin_ws, B.itile_b);
       uint32_t* iga = at<uint32_t>(bin_ws, B.ig_a);
       uint32_t* igb = at<uint32_t>(bin_ws, B.ig_b);
-      uint32_t* mask_sorted = at<uint32_t>(bin_ws, B.mask_sorted);
       uint32_t* bsum2 = at<uint32_t>(bin_ws, B.bsum2);
       uint32_t* boffs2 = at<uint32_t>(bin_ws, B.boffs2);
       // depth-sorted Gaussian indices: produced by stage 1 (gsr_forward_preprocess) in the geometry workspace
-      const uint32_t* didx_sorted = at<uint32_t>(geom_ws, (sort_passes(DEPTH_SORT_BITS) & 1) ? L.didx_b : L.didx_a);
+      const uint2* dval_sorted = at<uint2>(geom_ws, (sort_passes(DEPTH_SORT_BITS) & 1) ? L.didx_b : L.didx_a);
       {
         StageTimer t(p, GSR_STAGE_DUPLICATE, s);   // instances emitted in depth order
-        uint2* rect_sorted = at<uint2>(bin_ws, B.rect_sorted);
-        launch_gather_tiles(V, didx_sorted, bin, mask_sorted, rect_sorted, bsum2, s);
+        launch_count_tiles(V, dval_sorted, bin, bsum2, s);
         launch_scan_block_sums(bsum2, boffs2, boffs2 + B.nblocks2 + 1, nullptr, nullptr, nullptr, (int)B.nblocks2, s);
-        launch_emit_instances(V, I.grid_x, didx_sorted, mask_sorted, rect_sorted, boffs2, ita, iga, s);
+        launch_emit_instances(V, I.grid_x, dval_sorted, bin, boffs2, ita, iga, s);
       }
       if (int rc = check(p, s, "emit_instances")) return rc;
       bool in_b;

@@ -72,6 +72,29 @@ __device__ inline uint32_t bin_kth(uint32_t rect_wh, uint32_t mask, uint32_t k) 
   return (uint32_t)__ffs((int)m) - 1u;
 }
 
+// The rect of a small splat in 31 bits -- the second word of the depth sort's payload, so that the instance emission
+// streams instead of gathering BinInfo in depth order: first tile (13 bits: at most 8191 tiles), width - 1 (2 bits),
+// tile mask (16 bits, bit = y * width + x).  Rects wider than four tiles or of more than 16 carry PACK_FALLBACK.
+constexpr uint32_t PACK_FALLBACK = 0x80000000u;
+constexpr int PACK_W_SHIFT = 13, PACK_MASK_SHIFT = 15;
+__host__ __device__ inline uint32_t pack_rect(uint32_t rect_min, uint32_t rect_wh, uint32_t mask, uint32_t grid_x) {
+  const uint32_t w = rect_wh & 0xffffu, h = rect_wh >> 16;
+  const uint32_t tile0 = (rect_min >> 16) * grid_x + (rect_min & 0xffffu);
+  if (w == 0u || w > 4u || w * h > 16u || tile0 >= (1u << PACK_W_SHIFT)) return PACK_FALLBACK;
+  return tile0 | ((w - 1u) << PACK_W_SHIFT) | ((mask & 0xffffu) << PACK_MASK_SHIFT);
+}
+// back to (rect_min, rect_wh, mask) in the BinInfo convention; the height is the tallest a 16-bit mask of that width
+// allows (16 / w rows: every set bit stays inside, and bin_count / bin_kth only look at the mask for such rects)
+__host__ __device__ inline void unpack_rect(uint32_t packed, uint32_t grid_x, uint32_t& rect_min, uint32_t& rect_wh,
+                                            uint32_t& mask) {
+  const uint32_t tile0 = packed & ((1u << PACK_W_SHIFT) - 1u);
+  const uint32_t w = ((packed >> PACK_W_SHIFT) & 3u) + 1u;
+  const uint32_t y0 = tile0 / grid_x;
+  rect_min = (tile0 - y0 * grid_x) | (y0 << 16);
+  rect_wh = w | ((16u / w) << 16);
+  mask = packed >> PACK_MASK_SHIFT;
+}
+
 // Per-instance gradient row written by the compositing backward, summed per Gaussian by
 // the preprocess backward (atomic-free, bitwise reproducible).
 struct __attribute__((aligned(16))) GradRow {
@@ -107,8 +130,8 @@ struct GeomLayout {
                                                                              // [2] = entries of big_list
     dkey_a = o;     o = align_up(o + 4 * (size_t)P, 256);
     dkey_b = o;     o = align_up(o + 4 * (size_t)P, 256);
-    didx_a = o;     o = align_up(o + 4 * (size_t)P, 256);
-    didx_b = o;     o = align_up(o + 4 * (size_t)P, 256);
+    didx_a = o;     o = align_up(o + 8 * (size_t)P, 256);    // payload: (index, packed rect)
+    didx_b = o;     o = align_up(o + 8 * (size_t)P, 256);
     dsort = o;      o = align_up(o + 4 * (size_t)(1 << 9) * ((size_t)P / 4096 + 2) + 4096, 256);
     big_list = o;   o = align_up(o + 4 * (size_t)P, 256);    // Gaussians with more than ROWS_COOP instances (any order)
     bytes = o;
@@ -159,7 +182,7 @@ struct BinLayout {
   // mode 1
   size_t keys_a, keys_b, vals_a, vals_b;
   // mode 0
-  size_t mask_sorted, rect_sorted, bsum2, boffs2, itile_a, itile_b, ig_a, ig_b;
+  size_t bsum2, boffs2, itile_a, itile_b, ig_a, ig_b;
   size_t sort, bytes;
   uint32_t nblocks2;
   __host__ __device__ BinLayout(uint32_t R, uint32_t V, int mode) {
@@ -167,7 +190,7 @@ struct BinLayout {
     nblocks2 = (uint32_t)((v + PRE_BLOCK - 1) / PRE_BLOCK);
     size_t o = 0;
     keys_a = keys_b = vals_a = vals_b = 0;
-    mask_sorted = rect_sorted = bsum2 = boffs2 = itile_a = itile_b = ig_a = ig_b = 0;
+    bsum2 = boffs2 = itile_a = itile_b = ig_a = ig_b = 0;
     if (mode == 1) {
       keys_a = o; o = align_up(o + 8 * n, 256);
       keys_b = o; o = align_up(o + 8 * n, 256);
@@ -175,8 +198,6 @@ struct BinLayout {
       vals_b = o; o = align_up(o + 4 * n, 256);
       sort = o;   o = align_up(o + SortLayout((uint32_t)n).bytes, 256);
     } else {
-      mask_sorted = o; o = align_up(o + 4 * v, 256);
-      rect_sorted = o; o = align_up(o + 8 * v, 256);
       bsum2 = o;  o = align_up(o + 4 * (size_t)(nblocks2 + 1), 256);
       boffs2 = o; o = align_up(o + 4 * (size_t)(nblocks2 + 1) + 64, 256);
       itile_a = o; o = align_up(o + 4 * n, 256);

@@ -34,19 +34,21 @@ inline int sort_passes(int end_bit) { return (end_bit + RADIX_BITS - 1) / RADIX_
 void launch_identify_tile_ranges(uint32_t R, const uint64_t* keys, uint2* ranges, hipStream_t s);
 void launch_build_tile_order(int tiles, const uint2* ranges, uint32_t* order, hipStream_t s);
 void launch_compact_visible(int P, const BinInfo* bin, const uint32_t* block_vis_offs, const uint32_t* block_offs,
-                            uint32_t* slot_base, const uint32_t* depth_inv_min, uint32_t* dkey, uint32_t* didx, hipStream_t s);
-void launch_sort_extra_pass_u32(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, uint32_t n,
+                            uint32_t* slot_base, const uint32_t* depth_inv_min, int grid_x, uint32_t* dkey, uint2* dval,
+                            hipStream_t s);
+// (32-bit key, 64-bit value) pairs: the depth sort, whose payload is (index, packed rect)
+bool launch_sort_pairs_u32_v64(uint32_t* keys_a, uint2* vals_a, uint32_t* keys_b, uint2* vals_b, uint32_t n,
+                               int end_bit, void* scratch, hipStream_t s, const uint32_t* n_dev = nullptr);
+void launch_sort_extra_pass_u32(const uint32_t* kin, const uint2* vin, uint32_t* kout, uint2* vout, uint32_t n,
                                 const uint32_t* n_dev, int shift, int nbits, void* scratch, hipStream_t s);
 // The two-level binning sorts the visible Gaussians on (depth bits - smallest depth bits of the frame).  Three 8-bit
 // passes (24 bits: up to two binades of depth, e.g. 3 .. 12) are enqueued before the host knows the counts; a frame
 // that spans more gets the fourth 8-bit pass on bits 24..31 once the range has been read back with the counts.
 // (Three 9-bit passes were measured too: as slow as four 8-bit ones -- wider digits rank and scatter more slowly.)
 constexpr int DEPTH_SORT_BITS = 24;
-void launch_gather_tiles(uint32_t V, const uint32_t* didx, const BinInfo* bin, uint32_t* mask_sorted, uint2* rect_sorted,
-                         uint32_t* block_sums2, hipStream_t s);
-void launch_emit_instances(uint32_t V, int grid_x, const uint32_t* didx, const uint32_t* mask_sorted,
-                           const uint2* rect_sorted, const uint32_t* block_offs2, uint32_t* inst_tile, uint32_t* inst_g,
-                           hipStream_t s);
+void launch_count_tiles(uint32_t V, const uint2* dval, const BinInfo* bin, uint32_t* block_sums2, hipStream_t s);
+void launch_emit_instances(uint32_t V, int grid_x, const uint2* dval, const BinInfo* bin, const uint32_t* block_offs2,
+                           uint32_t* inst_tile, uint32_t* inst_g, hipStream_t s);
 void launch_reconstruct_keys(uint32_t R, const uint32_t* tile_sorted, const uint32_t* point_list, const BinInfo* bin,
                              uint64_t* keys, hipStream_t s);
 

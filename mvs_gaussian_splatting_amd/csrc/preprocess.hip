@@ -122,24 +122,57 @@ struct Activated {
   float qn;         // norm used for the normalisation (1 when not normalising)
   float op;         // activated opacity
 };
-__device__ inline void load_scale_rot(const GsrParams& p, int idx, Activated& a) {
+// the raw values are read first (all of a Gaussian's small loads are issued together, ahead of the arithmetic that
+// decides whether they are needed), activated later
+__device__ inline void load_scale_rot_raw(const GsrParams& p, int idx, Activated& a) {
   a.sc[0] = p.scales[3 * (size_t)idx];
   a.sc[1] = p.scales[3 * (size_t)idx + 1];
   a.sc[2] = p.scales[3 * (size_t)idx + 2];
+  a.q = reinterpret_cast<const float4*>(p.rotations)[idx];
+}
+__device__ inline void activate_scale_rot(const GsrParams& p, Activated& a) {
   if (p.act_flags & GSR_ACT_SCALE_EXP) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) a.sc[k] = expf(a.sc[k]);
   }
-  a.q = reinterpret_cast<const float4*>(p.rotations)[idx];
   a.qn = 1.0f;
   if (p.act_flags & GSR_ACT_ROT_NORMALIZE) {
     a.qn = fmaxf(sqrtf(a.q.x * a.q.x + a.q.y * a.q.y + a.q.z * a.q.z + a.q.w * a.q.w), 1e-12f);
     a.q.x = a.q.x / a.qn; a.q.y = a.q.y / a.qn; a.q.z = a.q.z / a.qn; a.q.w = a.q.w / a.qn;
   }
 }
+__device__ inline void load_scale_rot(const GsrParams& p, int idx, Activated& a) {
+  load_scale_rot_raw(p, idx, a);
+  activate_scale_rot(p, a);
+}
+__device__ inline float activate_opacity(const GsrParams& p, float o) {
+  return (p.act_flags & GSR_ACT_OPACITY_SIGMOID) ? 1.0f / (1.0f + expf(-o)) : o;
+}
 __device__ inline float load_opacity(const GsrParams& p, int idx) {
   const float o = p.opacities[idx];
   return (p.act_flags & GSR_ACT_OPACITY_SIGMOID) ? 1.0f / (1.0f + expf(-o)) : o;
+}
+
+// One Gaussian's 16 x 3 SH coefficients into registers, coefficient-major (k, channel): either the unsplit [P,16,3] row
+// (twelve 16-byte loads) or f_dc [P,1,3] + f_rest [P,15,3] (180-byte rows, 4-byte aligned: the compiler still emits
+// 16-byte loads in unaligned access mode).  With D = 0 only the DC term is read.
+__device__ inline void load_sh_row48(const GsrParams& p, int idx, float* __restrict__ f) {
+  if (p.shs_rest) {
+    const float* __restrict__ dc = p.shs + 3 * (size_t)idx;
+    const float* __restrict__ rr = p.shs_rest + (size_t)idx * 45;
+    f[0] = dc[0]; f[1] = dc[1]; f[2] = dc[2];
+    if (p.D > 0) {
+#pragma unroll
+      for (int i = 0; i < 45; ++i) f[3 + i] = rr[i];
+    }
+  } else {
+    const float4* s4 = reinterpret_cast<const float4*>(p.shs + (size_t)idx * 48);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const float4 v = s4[k];
+      f[4 * k] = v.x; f[4 * k + 1] = v.y; f[4 * k + 2] = v.z; f[4 * k + 3] = v.w;
+    }
+  }
 }
 
 // Split SH inputs: f_rest is [P,15,3] (180-byte rows, not 16-byte aligned per row).  A wave's 64 rows are
@@ -202,6 +235,12 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
   float px = 0.f, py = 0.f, pz = 0.f;
   Proj pr;
   pr.a = pr.c = 1.0f;
+  Activated act;
+  float op_raw = 0.0f;
+  // SH rows held in registers: the M = 16 layouts (split or not); other M read their coefficients in place
+  const bool sh_regs = !p.colors_precomp && (p.shs_rest != nullptr || p.M == 16);
+  bool sh_early = false;
+  float shrow[48];
 
   // ---- geometry: cull, project, cov3D -> cov2D -> conic, radius, tile rect -----------------------
   if (idx < p.P) {
@@ -209,6 +248,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
     load_mat(p.viewmatrix, V);
     load_mat(p.projmatrix, Mx);
     px = p.means3D[3 * (size_t)idx + 0]; py = p.means3D[3 * (size_t)idx + 1]; pz = p.means3D[3 * (size_t)idx + 2];
+    // every small per-Gaussian load goes out with the position: one memory latency instead of three in a row
+    // (scales / rotation after the near-plane test, opacity after the colour) for 32 bytes that nearly every
+    // Gaussian needs anyway
+    if (!p.cov3D_precomp) load_scale_rot_raw(p, idx, act);
+    op_raw = p.opacities[idx];
     const float vx = V.m[0] * px + V.m[4] * py + V.m[8] * pz + V.m[12];
     const float vy = V.m[1] * px + V.m[5] * py + V.m[9] * pz + V.m[13];
     const float vz = V.m[2] * px + V.m[6] * py + V.m[10] * pz + V.m[14];
@@ -218,14 +262,19 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
       const float hw = Mx.m[3] * px + Mx.m[7] * py + Mx.m[11] * pz + Mx.m[15];
       const float p_w = 1.0f / (hw + 0.0000001f);
       const float ndc_x = hx * p_w, ndc_y = hy * p_w;
+      // A Gaussian whose centre is on the screen is all but certainly kept: its SH row is requested now, so that the
+      // 192 bytes arrive while the covariance is projected (the rest -- centre outside, splat reaching in -- load late).
+      if (sh_regs && fabsf(ndc_x) < 1.0f && fabsf(ndc_y) < 1.0f) {
+        sh_early = true;
+        load_sh_row48(p, idx, shrow);
+      }
 
       float cov[6];
       if (p.cov3D_precomp) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) cov[k] = p.cov3D_precomp[6 * (size_t)idx + k];
       } else {
-        Activated act;
-        load_scale_rot(p, idx, act);
+        activate_scale_rot(p, act);
         cov3d_from_scale_rot(act.sc[0], act.sc[1], act.sc[2], p.scale_modifier, act.q.x, act.q.y, act.q.z, act.q.w, cov);
       }
       const float fx = (float)W / (2.0f * p.tan_fovx), fy = (float)H / (2.0f * p.tan_fovy);
@@ -267,7 +316,6 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
   }
 
   // ---- colour ------------------------------------------------------------------------------------
-  const bool split = p.shs_rest != nullptr;
   if (vis) {
     float rgb[3];
     uint32_t flags = 0;
@@ -279,29 +327,12 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
       const float dx = px - p.campos[0], dy = py - p.campos[1], dz = pz - p.campos[2];
       const float ln = sqrtf(dx * dx + dy * dy + dz * dz);
       const float ux = dx / ln, uy = dy / ln, uz = dz / ln;
-      if (split) {
-        // f_rest rows are 180 bytes (4-byte aligned): the compiler still emits 16-byte loads (unaligned
-        // access mode), the same access shape as the unsplit [P,16,3] row
-        const float* __restrict__ dc = p.shs + 3 * (size_t)idx;
-        const float* __restrict__ rr = p.shs_rest + (size_t)idx * REST_ROW;
-        float row[REST_ROW];
-        if (p.D > 0) {
-#pragma unroll
-          for (int i = 0; i < REST_ROW; ++i) row[i] = rr[i];
-        }
-        eval_sh(p.D, [&](int k, int ch) { return k == 0 ? dc[ch] : row[3 * (k - 1) + ch]; }, ux, uy, uz, rgb);
+      if (sh_regs) {
+        if (!sh_early) load_sh_row48(p, idx, shrow);
+        eval_sh(p.D, [&](int k, int ch) { return shrow[3 * k + ch]; }, ux, uy, uz, rgb);
       } else {
         const float* __restrict__ s = p.shs + (size_t)idx * p.M * 3;
-        if (p.M == 16) {
-          float4 v[12];
-          const float4* s4 = reinterpret_cast<const float4*>(s);
-#pragma unroll
-          for (int k = 0; k < 12; ++k) v[k] = s4[k];
-          const float* f = reinterpret_cast<const float*>(v);
-          eval_sh(p.D, [&](int k, int ch) { return f[3 * k + ch]; }, ux, uy, uz, rgb);
-        } else {
-          eval_sh(p.D, [&](int k, int ch) { return s[3 * k + ch]; }, ux, uy, uz, rgb);
-        }
+        eval_sh(p.D, [&](int k, int ch) { return s[3 * k + ch]; }, ux, uy, uz, rgb);
       }
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
@@ -310,7 +341,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
         rgb[ch] = fmaxf(rgb[ch], 0.0f);
       }
     }
-    const float op = load_opacity(p, idx);
+    const float op = activate_opacity(p, op_raw);
     // conservative half-extent of the region where alpha = op*exp(power) can reach 1/255
     float ext_x = -1.0f, ext_y = -1.0f;
     if (op >= ALPHA_MIN) {

@@ -737,3 +737,33 @@ def test_depth_sort_of_a_frame_spanning_more_than_24_bits(gpu_device, pinned):
     robust = aux["margin"] > 1e-4
     err = ((img - col).abs() / col.abs().clamp(min=1.0)).max(dim=0).values
     assert float(err[robust].max()) <= 1e-5
+
+
+def test_packed_rect_payload_boundaries(gpu_device):
+    """The depth sort carries (index, packed rect) for rects of width <= 4 and <= 16 tiles and a fall-back marker for the
+    rest (gsr_common.h pack_rect): a cloud whose rects straddle both limits must give the oracle's lists in the two-level
+    mode, the same lists as the 64-bit-key mode, and the same picture with the tile masks of the culled mode."""
+    from gpu_util import forward_with_state, product_settings
+    model, cam, bg, _ = small_scene(P=3000, sh_degree=1, width=352, height=240)
+    g = torch.Generator().manual_seed(21)
+    # screen rects from one tile to ~12 tiles across, one third of them needles (tall / wide bounding boxes after the culling)
+    model._scaling[:] = torch.log(torch.exp(torch.rand(3000, 1, generator=g) * math.log(40.0)) * 0.01).expand(3000, 3)
+    model._scaling[:1000, 1:] -= math.log(12.0)
+    col, radii, aux = _oracle_forward(model, cam, bg, 1)
+    rect = aux["pre"]["v_rect"].numpy()[aux["pre"]["keep"].numpy()]
+    w, h = rect[:, 2] - rect[:, 0], rect[:, 3] - rect[:, 1]
+    packs = (w <= 4) & (w * h <= 16)
+    assert packs.sum() > 100 and (w > 4).sum() > 100 and ((w <= 4) & (w * h > 16)).sum() >= 1
+    assert ((w == 4) & (h == 4)).sum() >= 1 and ((w == 5) | (h == 5)).sum() >= 1
+    st = product_settings(cam, bg, 1, gpu_device)
+    o = {m: forward_with_state(gpu_device, st, model.get_xyz, model.get_opacity, shs=model.get_features,
+                               scales=model.get_scaling, rotations=model.get_rotation, binning_mode=m) for m in (0, 1, 2)}
+    assert np.array_equal(o[0]["keys"], aux["keys"]) and np.array_equal(o[0]["point_list"], aux["point_list"])
+    assert np.array_equal(o[0]["ranges"], aux["ranges"])
+    assert np.array_equal(o[1]["keys"], o[0]["keys"]) and np.array_equal(o[1]["point_list"], o[0]["point_list"])
+    # culled lists: a sub-sequence of the full ones per tile, and no visible difference (dropped instances never pass alpha)
+    assert o[2]["R"] < o[0]["R"]
+    full = set(zip((o[0]["keys"] >> np.uint64(32)).tolist(), o[0]["point_list"].tolist()))
+    assert set(zip((o[2]["keys"] >> np.uint64(32)).tolist(), o[2]["point_list"].tolist())) <= full
+    assert np.all(o[2]["keys"][1:] >= o[2]["keys"][:-1])
+    assert torch.equal(o[2]["color"], o[0]["color"])
