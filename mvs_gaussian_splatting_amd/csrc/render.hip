@@ -92,20 +92,24 @@ __device__ inline uint32_t subblock_mask(float gx, float gy, float ex, float ey,
 //    nka = -0.5 log2e cxx,  kk = cxy / cxx,  nkd = -0.5 log2e / cov_yy.
 // Both terms are <= 0 in float32 whatever the rounding, so the reference's "power > 0 -> skip" guard (Appendix A.4)
 // can never fire -- it only ever fired on rounding noise of the expanded form -- and costs no compare here.
+// The opacity rides in the exponent: alpha = opacity * exp(power) = exp2(log2(opacity) + log2e * power) -- the addend
+// of a multiply that becomes an fma, one instruction less per pair than the product (v_log_f32 is good to an ulp, the
+// sum is at most ~8 in magnitude: alpha moves by < 5e-7 relative).
 struct LdsRec {
   float4 A;   // x, y, nka, kk
-  float4 B;   // nkd, opacity, r, g
+  float4 B;   // nkd, log2(opacity), r, g
 };
 __device__ inline void make_lds(const Staged& st, LdsRec& o) {
   o.A = make_float4(st.q0.x, st.q0.y, (-0.5f * LOG2E) * st.q0.z, st.kk);
-  o.B = make_float4((-0.5f * LOG2E) * st.isyy, st.q1.y, st.q1.z, st.q1.w);
+  o.B = make_float4((-0.5f * LOG2E) * st.isyy, __builtin_amdgcn_logf(st.q1.y), st.q1.z, st.q1.w);
 }
-// the same five operations in the forward and in the backward: both must take the same alpha >= 1/255 decisions
-__device__ __forceinline__ float pair_p2(float dx, float dy, float nka, float kk, float nkd) {
+// log2(alpha before the clamp).  The same five operations in the forward and in the backward: both must take the same
+// alpha >= 1/255 decisions
+__device__ __forceinline__ float pair_p2(float dx, float dy, float nka, float kk, float nkd, float lo) {
 #pragma clang fp contract(off)
   const float u = __builtin_fmaf(kk, dy, dx);
   const float s = nka * u;
-  const float v = (nkd * dy) * dy;
+  const float v = __builtin_fmaf(nkd * dy, dy, lo);
   return __builtin_fmaf(s, u, v);
 }
 
@@ -172,22 +176,22 @@ __device__ inline uint32_t miniblock_mask(float mx, float my, float cxx, float k
 // One (instance, pixel) pair of the forward.  T > 0 while the pixel is live; a pixel that saturates keeps its final
 // transmittance with the sign flipped (outside the image: T = 0), so every later test_T = T (1 - alpha) <= 0 < 1e-4
 // keeps it out of the blend without a separate flag.
+// `token` is what a contributing pair leaves in `last` (the list entry: converted to a list position once per round).
 template <bool TRACK, bool CLAMP>
-__device__ __forceinline__ void blend_pair(const float4 a, const float4 b, const float cb, const uint32_t pos1,
+__device__ __forceinline__ void blend_pair(const float4 a, const float4 b, const float cb, const uint32_t token,
                                            const float pxf, const float pyf, float& T, float& Cr, float& Cg, float& Cb,
                                            uint32_t& last) {
   const float dx = a.x - pxf, dy = a.y - pyf;
-  const float p2 = pair_p2(dx, dy, a.z, a.w, b.x);
-  float alpha = b.y * __builtin_amdgcn_exp2f(p2);
+  float alpha = __builtin_amdgcn_exp2f(pair_p2(dx, dy, a.z, a.w, b.x, b.y));
   if (CLAMP) alpha = fminf(ALPHA_MAX, alpha);     // opacity <= 0.99 cannot reach the clamp: exp2(p2 <= 0) <= 1
   if (alpha >= ALPHA_MIN) {
-    const float test_T = T * (1.0f - alpha);
+    const float test_T = __builtin_fmaf(-alpha, T, T);      // T (1 - alpha), rounded once
     if (!(test_T < T_STOP)) {
       const float w = alpha * T;
       Cr = fmaf(b.z, w, Cr);
       Cg = fmaf(b.w, w, Cg);
       Cb = fmaf(cb, w, Cb);
-      if (TRACK) last = pos1;
+      if (TRACK) last = token;
       T = test_T;
     } else {
       T = -fabsf(T);      // saturates here (or is parked already)
@@ -199,7 +203,7 @@ __device__ __forceinline__ void blend_pair(const float4 a, const float4 b, const
 // addressed with a quarter of it).  One-deep software pipeline: the next list entry and the next record are fetched
 // while the current pair is evaluated.
 template <bool TRACK, bool CLAMP>
-__device__ __forceinline__ void walk_lists(const uint16_t* __restrict__ mylist, const uint32_t nmax, const uint32_t base1,
+__device__ __forceinline__ void walk_lists(const uint16_t* __restrict__ mylist, const uint32_t nmax,
                                            const char* sA, const char* sB, const char* sC, const float pxf,
                                            const float pyf, float& T, float& Cr, float& Cg, float& Cb, uint32_t& last) {
   auto ldA = [&](uint32_t e) { return *reinterpret_cast<const float4*>(sA + e); };
@@ -213,14 +217,14 @@ __device__ __forceinline__ void walk_lists(const uint16_t* __restrict__ mylist, 
     const float4 a1 = ldA(e1), b1 = ldB(e1);
     const float c1 = ldC(e1);
     const uint32_t e2 = mylist[i + 2];
-    blend_pair<TRACK, CLAMP>(a0, b0, c0, base1 + (e0 >> 4), pxf, pyf, T, Cr, Cg, Cb, last);
+    blend_pair<TRACK, CLAMP>(a0, b0, c0, e0, pxf, pyf, T, Cr, Cg, Cb, last);
     a0 = a1; b0 = b1; c0 = c1;
     e0 = e1; e1 = e2;
   }
 }
 
 template <bool STATS, bool TRACK>
-__global__ __launch_bounds__(256, 8) void render_fwd_kernel(int W, int H, int grid_x, int cull_miniblocks,
+__global__ __launch_bounds__(256, TRACK ? 7 : 8) void render_fwd_kernel(int W, int H, int grid_x, int cull_miniblocks,
                                                          const uint32_t* __restrict__ tile_order,
                                                          const uint2* __restrict__ ranges,
                                                          const uint32_t* __restrict__ point_list,
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(256, 8) void render_fwd_kernel(int W, int H, int gr
   const uint32_t start = range.x, len = range.y - range.x;
   if (tid == 0) {
     sA[QDUMMY] = make_float4(0.f, 0.f, 0.f, 0.f);
-    sB[QDUMMY] = make_float4(0.f, 0.f, 0.f, 0.f);
+    sB[QDUMMY] = make_float4(0.f, -__builtin_inff(), 0.f, 0.f);      // log2(opacity) = -inf: alpha = exp2(-inf) = 0
     sC[QDUMMY] = 0.0f;
   }
   // this 16-lane group's mini-block: row / column of 4x4 blocks inside the tile (bit 4 * blk_r + blk_c of the reach mask)
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(256, 8) void render_fwd_kernel(int W, int H, int gr
       incl[r] = wave_incl_scan_dpp(own[r]);
     }
     if (lane == WAVE - 1) sCnt[wid] = make_uint4(incl[0], incl[1], incl[2], incl[3]);
-    const bool opaque = have && lr.B.y > ALPHA_MAX;
+    const bool opaque = have && st.q1.y > ALPHA_MAX;
     const bool wave_opaque = __builtin_amdgcn_ballot_w64(opaque) != 0ull;
     if (lane == 0) sFlag[0][wid] = wave_opaque ? 1u : 0u;
     __syncthreads();
@@ -339,8 +343,10 @@ __global__ __launch_bounds__(256, 8) void render_fwd_kernel(int W, int H, int gr
     // ---- (d) every 16-lane group walks its own list --------------------------------------------------------------
     if (STATS) { st_pairs += (q == 0) ? n_lane : 0u; st_evals += (lane == 0) ? nmax : 0u; }
 #ifndef GSR_EXPERIMENT_NO_WALK     // tuning experiment: staging / culling / compaction only
-    if (clamp) walk_lists<TRACK, true>(mylist, nmax, base + 1u, (const char*)sA, (const char*)sB, (const char*)sC, pxf, pyf, T, Cr, Cg, Cb, last);
-    else       walk_lists<TRACK, false>(mylist, nmax, base + 1u, (const char*)sA, (const char*)sB, (const char*)sC, pxf, pyf, T, Cr, Cg, Cb, last);
+    uint32_t last_e = 0xffffffffu;        // list entry (16 * slot) of the round's last contributor
+    if (clamp) walk_lists<TRACK, true>(mylist, nmax, (const char*)sA, (const char*)sB, (const char*)sC, pxf, pyf, T, Cr, Cg, Cb, last_e);
+    else       walk_lists<TRACK, false>(mylist, nmax, (const char*)sA, (const char*)sB, (const char*)sC, pxf, pyf, T, Cr, Cg, Cb, last_e);
+    if (TRACK && last_e != 0xffffffffu) last = base + 1u + (last_e >> 4);
 #else
     if (clamp && nmax == 0xffffffffu) T = 0.0f;
 #endif
@@ -528,16 +534,15 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, floa
       const uint32_t pos1 = cur_lo + (uint32_t)j + 1u;
       // per-lane partial sums over the sub-blocks; un-scaled forms (constants applied after the reduction):
       //   g_mx = sum h dx, g_my = sum h dy (first moments), g_xx = sum h dx^2, g_xy = sum h dx dy,
-      //   g_yy = sum h dy^2 with h = opacity*G*dL_dalpha;  g_op = sum G*dL_dalpha;  g_r/g/b = sum alpha*T*dL_dpix
+      //   g_yy = sum h dy^2 with h = opacity*G*dL_dalpha;  g_op = sum h (= opacity * dL_dopacity);  g_r/g/b = sum alpha*T*dL_dpix
       float g_mx = 0.f, g_my = 0.f, g_xx = 0.f, g_xy = 0.f, g_yy = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
       bool any = false;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (mj & (1u << k)) {
           const float dx = a.x - ((k & 1) ? pxf1 : pxf0), dy = a.y - ((k >> 1) ? pyf1 : pyf0);
-          const float p2 = pair_p2(dx, dy, a.z, a.w, b.x);
-          const float G = __builtin_amdgcn_exp2f(p2);
-          float alpha = b.y * G;
+          const float alpha_raw = __builtin_amdgcn_exp2f(pair_p2(dx, dy, a.z, a.w, b.x, b.y));   // opacity * G
+          float alpha = alpha_raw;
           if (mj & 16u) alpha = fminf(ALPHA_MAX, alpha);
           const bool ok = (pos1 <= last[k]) && (alpha >= ALPHA_MIN);
           if (ok) {
@@ -551,9 +556,8 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, floa
             g_r = fmaf(dch, dpr[k], g_r);
             g_g = fmaf(dch, dpg[k], g_g);
             g_b = fmaf(dch, dpb[k], g_b);
-            const float gd = G * dL_dalpha;
-            g_op += gd;
-            const float h = b.y * gd;
+            const float h = alpha_raw * dL_dalpha;      // opacity * G * dL_dalpha: the clamp passes the gradient on
+            g_op += h;                                     // (sum G dL_dalpha = this / opacity, applied to the row)
             const float hx = h * dx, hy = h * dy;
             g_mx += hx;                                    // first moments; the conic is applied per Gaussian
             g_my += hy;                                    // by preprocess_bwd
@@ -568,12 +572,13 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, floa
         const float s1 = wave_sum4(g_yy, g_r, g_op, g_g);     // rows: yy, op, r, g
         const float s2 = row_sum16(fold16(fold32(g_b, g_b), 0.0f));   // row 0 (and 2): b
         const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)slot, j);
+        const float inv_op_j = __builtin_amdgcn_exp2f(-b.y);     // 1 / opacity from the staged log2(opacity)
         float* dst = reinterpret_cast<float*>(rows + sj);
         if ((lane & 15) == 0) {
           const int r = lane >> 4;
           const float f0 = r < 2 ? 1.0f : (r == 2 ? -0.5f : -1.0f);
           dst[r] = s0 * f0;                                    // Mx, My (first moments), dcxx, dcxy
-          const float f1 = r == 0 ? -0.5f : 1.0f;
+          const float f1 = r == 0 ? -0.5f : (r == 1 ? inv_op_j : 1.0f);
           dst[4 + r] = s1 * f1;                                // dcyy, dop, dr, dg
           if (r == 0) {
             dst[8] = s2;
