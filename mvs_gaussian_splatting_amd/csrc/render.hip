@@ -405,6 +405,17 @@ __device__ inline float row_sum16(float v) {
   v = dpp_add<0x140>(v);   // row_mirror
   return v;
 }
+// one value summed over the wave with DPP alone (six half-rate adds; the swap-based folds below pay off only when they
+// carry two values at once): every lane of row 3 (lanes 48..63) ends with the total
+__device__ inline float wave_sum1_row3(float v) {
+  v = row_sum16(v);
+  // v_add_f32_dpp leaves the rows outside row_mask untouched: one instruction per step (the builtin form, with its
+  // separate `old` operand, costs three).  The s_nop covers the VALU-write -> DPP-read hazard the assembler cannot see.
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+               : "+v"(v));
+  return v;
+}
 // lanes 0..31 end with x[i] + x[i+32], lanes 32..63 with y[i-32] + y[i]
 __device__ inline float fold32(float x, float y) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
@@ -570,7 +581,7 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, floa
       if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
         const float s0 = wave_sum4(g_mx, g_xx, g_my, g_xy);   // rows: mx, my, xx, xy
         const float s1 = wave_sum4(g_yy, g_r, g_op, g_g);     // rows: yy, op, r, g
-        const float s2 = row_sum16(fold16(fold32(g_b, g_b), 0.0f));   // row 0 (and 2): b
+        const float s2 = wave_sum1_row3(g_b);                  // row 3: b
         const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)slot, j);
         const float inv_op_j = __builtin_amdgcn_exp2f(-b.y);     // 1 / opacity from the staged log2(opacity)
         float* dst = reinterpret_cast<float*>(rows + sj);
@@ -580,10 +591,8 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, floa
           dst[r] = s0 * f0;                                    // Mx, My (first moments), dcxx, dcxy
           const float f1 = r == 0 ? -0.5f : (r == 1 ? inv_op_j : 1.0f);
           dst[4 + r] = s1 * f1;                                // dcyy, dop, dr, dg
-          if (r == 0) {
-            dst[8] = s2;
-            row_flags[sj] = 1;
-          }
+          if (r == 0) row_flags[sj] = 1;
+          if (r == 3) dst[8] = s2;
         }
       }
     }

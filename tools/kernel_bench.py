@@ -24,8 +24,20 @@ for _ in range(iters):
     torch.cuda.synchronize()
     tf += t0.elapsed_time(t1); tb += t1.elapsed_time(t2)
 res = prof.collect()
-s.params.profile = None
 print(f"{cfg}: P={s.P} R={s.R} visible={int((s.radii > 0).sum())} fwd={tf / iters:.3f} ms bwd={tb / iters:.3f} ms")
 for k, (ms, n) in res.items():
     if n:
         print(f"  {k:24s} {ms / n:8.4f} ms")
+# the forward-only variant (what render() runs under no_grad: no backward state is kept)
+s.params.forward_only = 1
+s.forward()
+torch.cuda.synchronize()
+tf = 0.0
+for _ in range(iters):
+    t0.record(); s.forward(); t1.record()
+    torch.cuda.synchronize()
+    tf += t0.elapsed_time(t1)
+res = prof.collect()
+s.params.profile = None
+s.params.forward_only = 0
+print(f"forward-only: fwd={tf / iters:.3f} ms  " + "  ".join(f"{k}={ms / n:.4f}" for k, (ms, n) in res.items() if n))
