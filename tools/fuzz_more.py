@@ -1,0 +1,26 @@
+"""Extra fuzz seeds of tests/test_gpu_parity.py::test_fuzz_random_small_scenes_forward_and_backward (not part of the
+suite: a one-off soak after kernel changes):  python tools/fuzz_more.py 8 48"""
+import os
+import sys
+import traceback
+
+import torch
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+sys.path.insert(0, os.path.join(root, "tests"))
+import test_gpu_parity as t  # noqa: E402
+
+lo, hi = int(sys.argv[1]), int(sys.argv[2])
+dev = torch.device("cuda:0")
+bad = []
+for seed in range(lo, hi):
+    try:
+        t.test_fuzz_random_small_scenes_forward_and_backward(dev, seed)
+        print("seed", seed, "ok", flush=True)
+    except Exception:      # noqa: BLE001
+        bad.append(seed)
+        print("seed", seed, "FAILED", flush=True)
+        traceback.print_exc()
+print("failed seeds:", bad)
+sys.exit(1 if bad else 0)
