@@ -79,9 +79,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void duplicate_with_keys_kernel(int P, i
 // Two-level binning (mode 0).  Same point lists and tile ranges as sorting 64-bit (tile, depth) keys, for
 // ~2.5x less memory traffic: the per-instance data that goes through a multi-pass sort shrinks from 12 bytes x
 // 5-6 passes to 8 bytes x 2 passes, because the depth order is established once per Gaussian, not per instance.
-//   1. compact_visible      : (depth bits, index) of the visible Gaussians, in index order
-//   2. sort by depth        : stable LSD radix sort of V (u32, u32) pairs, 32 bits
-//   3. gather_tiles + scan  : tiles_touched in depth order -> first slot of every Gaussian (depth-major slots)
+//   1. compact_visible      : (depth bits - nearest depth bits, (index, packed rect)) of the visible Gaussians, index order
+//   2. sort by depth        : stable LSD radix sort of V (u32 key, 8-byte payload) pairs on 24 bits (gsr_launch.h:
+//                             DEPTH_SORT_BITS; the top 8 bits in a fourth pass only when a frame needs them)
+//   3. count_tiles + scan   : tiles_touched in depth order (from the payload) -> first slot of every 256 Gaussians
 //   4. emit_instances       : (tile id, index) per overlapped tile, y outer / x inner, in depth order
 //   5. sort by tile         : stable sort on ceil(log2 T) bits -> lists ordered by (tile, depth, index)
 // Stability of both sorts reproduces the tie order of a stable 64-bit sort of index-ordered pairs.

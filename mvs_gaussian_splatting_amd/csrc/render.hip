@@ -183,7 +183,7 @@ __device__ __forceinline__ void blend_pair(const float4 a, const float4 b, const
                                            uint32_t& last) {
   const float dx = a.x - pxf, dy = a.y - pyf;
   float alpha = __builtin_amdgcn_exp2f(pair_p2(dx, dy, a.z, a.w, b.x, b.y));
-  if (CLAMP) alpha = fminf(ALPHA_MAX, alpha);     // opacity <= 0.99 cannot reach the clamp: exp2(p2 <= 0) <= 1
+  if (CLAMP) alpha = fminf(ALPHA_MAX, alpha);     // opacity <= 0.99 stays at or below 0.99 (to the ulp of v_log / v_exp): no clamp
   if (alpha >= ALPHA_MIN) {
     const float test_T = __builtin_fmaf(-alpha, T, T);      // T (1 - alpha), rounded once
     if (!(test_T < T_STOP)) {
