@@ -599,7 +599,271 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, floa
   }
 }
 
-__global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE, 6) void render_bwd_kernel(int W, int H, int grid_x, int num_tiles,
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward, list-driven (the kernel that runs): one wave per tile, every 16-lane group (a DPP row) owns one 8x8
+// sub-block -- lane q of the group holds the 2x2 pixel quad (2 (q & 3), 2 (q >> 2)) of it -- and walks its OWN list of
+// the round's instances that reach the sub-block, back to front.  One wave instruction works on four different
+// (instance, sub-block) pairs, and the per-instance scalar control of the wave-per-instance loop above (mask read-out,
+// four bit tests, EXEC juggling: 45 % of that kernel's time) is gone.  The nine sums of a pair are folded
+// over the 16-lane row with DPP only and added into the wave's LDS slab [instance][9], from which the staging lanes
+// write whole 48-byte rows at the end of the round.  Still no atomics, still bitwise reproducible: a slab word is
+// added to in list order, and when two groups hold the same instance at the same step they go in group order.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int SB_DUMMY = WAVE;                 // LDS slot of the all-zero record the lists are padded with
+constexpr int SB_LIST = WAVE + 8;              // list capacity (entries past the longest list are read, never used)
+constexpr int SB_SLAB = 5 * 2 * WAVE;          // doubles: 65 x 9 = 585 used, a multiple of 64 x 16 bytes for the zero-fill
+struct SbLds {
+  float4 A[WAVE + 1];
+  float4 B[WAVE + 1];
+  float C[WAVE + 4];
+  uint16_t list[4][SB_LIST];
+  // The (at most four) sub-block partial sums of a row are added in double: the order in which the groups reach an
+  // instance depends on what else is in the round, and a float sum would make the last bit of a gradient depend on the
+  // binning mode (a double sum of four floats is exact unless their exponents span more than 2^29).
+  double slab[SB_SLAB];
+};
+
+// lanes of the banks in BANK_MASK (bank = 4 consecutive lanes of a 16-lane row) take b, the others keep a
+template <int BANK_MASK>
+__device__ __forceinline__ float dpp_merge(float a, float b) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(a), __float_as_int(b), 0xE4, 0xf, BANK_MASK, false));
+}
+// Sums of nine values over each 16-lane row.  Result: n0 banks (0,1,2,3) = sums of (v0, v2, v1, v3), n1 banks = sums of
+// (v4, v6, v5, v7), n2 every bank = sum of v8 (each sum in all four lanes of its bank).
+__device__ __forceinline__ void row_fold9(const float (&v)[9], float& n0, float& n1, float& n2) {
+  float w[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) w[i] = dpp_add<0x128>(v[i]);            // row_ror:8  -> lanes l and l+8 agree
+  float m0 = dpp_merge<0xc>(w[0], w[1]);                              // lanes 0-7: v0, lanes 8-15: v1
+  float m1 = dpp_merge<0xc>(w[2], w[3]);
+  float m2 = dpp_merge<0xc>(w[4], w[5]);
+  float m3 = dpp_merge<0xc>(w[6], w[7]);
+  float m4 = w[8];
+  m0 = dpp_add<0x141>(m0); m1 = dpp_add<0x141>(m1); m2 = dpp_add<0x141>(m2);    // row_half_mirror: lanes i and 7-i
+  m3 = dpp_add<0x141>(m3); m4 = dpp_add<0x141>(m4);
+  n0 = dpp_merge<0xa>(m0, m1);                                        // banks 0,2 from m0 (v0 | v1), banks 1,3 from m1
+  n1 = dpp_merge<0xa>(m2, m3);
+  n2 = m4;
+  n0 = dpp_add<0xB1>(n0); n1 = dpp_add<0xB1>(n1); n2 = dpp_add<0xB1>(n2);      // quad_perm [1,0,3,2]
+  n0 = dpp_add<0x4E>(n0); n1 = dpp_add<0x4E>(n1); n2 = dpp_add<0x4E>(n2);      // quad_perm [2,3,0,1]
+}
+
+__device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, int W, int H, int grid_x,
+                                                     const uint2* __restrict__ ranges,
+                                                     const uint32_t* __restrict__ point_list,
+                                                     const GeomRec* __restrict__ rec,
+                                                     const uint32_t* __restrict__ slot_base, const float* __restrict__ bg,
+                                                     const float* __restrict__ final_T,
+                                                     const uint32_t* __restrict__ n_contrib,
+                                                     const uint32_t* __restrict__ tile_max,
+                                                     const float* __restrict__ dL_dpix, GradRow* __restrict__ rows,
+                                                     uint8_t* __restrict__ row_flags) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int grp = lane >> 4, q = lane & 15;
+  const int tile_x = tile % grid_x, tile_y = tile / grid_x;
+  const float tx0 = (float)(tile_x * TILE), ty0 = (float)(tile_y * TILE);
+  // the lane's 2x2 quad inside sub-block grp (sub-block k: x index k & 1, y index k >> 1, as subblock_mask numbers them)
+  const int px0 = tile_x * TILE + 8 * (grp & 1) + 2 * (q & 3), py0 = tile_y * TILE + 8 * (grp >> 1) + 2 * (q >> 2);
+  // dx = mean - pixel is formed by ONE subtraction from the exact integer coordinate, as in the forward and the reference
+  float pxf0 = (float)px0, pxf1 = (float)(px0 + 1), pyf0 = (float)py0, pyf1 = (float)(py0 + 1);
+  asm volatile("" : "+v"(pxf0), "+v"(pxf1), "+v"(pyf0), "+v"(pyf1));      // keep them in registers
+  const size_t HW = (size_t)W * H;
+  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+  // per pixel: T (running transmittance in front of the current instance), Bk = sum over the
+  // instances behind of (c.dL_dpix)*alpha*T  +  T_final*(bg.dL_dpix)
+  float T[4], Bk[4], dpr[4], dpg[4], dpb[4];
+  uint32_t last[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int px = px0 + (k & 1), py = py0 + (k >> 1);
+    const bool in = px < W && py < H;
+    const size_t pix = (size_t)py * W + px;
+    T[k] = in ? final_T[pix] : 0.0f;
+    last[k] = in ? n_contrib[pix] : 0u;
+    dpr[k] = in ? dL_dpix[pix] : 0.0f;
+    dpg[k] = in ? dL_dpix[HW + pix] : 0.0f;
+    dpb[k] = in ? dL_dpix[2 * HW + pix] : 0.0f;
+    Bk[k] = T[k] * (bg0 * dpr[k] + bg1 * dpg[k] + bg2 * dpb[k]);
+  }
+  const uint2 range = ranges[tile];
+  const uint32_t start = range.x;
+  uint32_t hi = min(range.y - range.x, tile_max[tile]);   // instances past the last contributor get no gradient
+  // the same per 8x8 sub-block (= 16-lane row): a sub-block behind an opaque surface stops long before the rest of the tile
+  uint32_t sub_last[4];
+  {
+    uint32_t mx = max(max(last[0], last[1]), max(last[2], last[3]));
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, WAVE));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sub_last[k] = (uint32_t)__builtin_amdgcn_readlane((int)mx, 16 * k);
+  }
+  if (lane == 0) {
+    L.A[SB_DUMMY] = make_float4(0.f, 0.f, 0.f, 0.f);
+    L.B[SB_DUMMY] = make_float4(0.f, -__builtin_inff(), 0.f, 0.f);      // log2(opacity) = -inf: alpha = 0
+    L.C[SB_DUMMY] = 0.0f;
+  }
+  // where this lane's fold results go (row_fold9): banks (0,1,2,3) of n0 / n1 hold values (0,2,1,3) (+4)
+  const int bank = q >> 2, sel = q & 3;
+  const int vsel = (bank == 1) ? 2 : (bank == 2 ? 1 : bank);
+  // slab word this lane adds to: n0 -> values 0..3, n1 -> 4..7, n2 -> 8 (bank 0 only); -1: none
+  const int acc_lane = sel == 0 ? vsel : (sel == 1 ? 4 + vsel : ((sel == 2 && bank == 0) ? 8 : -1));
+  const uint16_t* mylist = &L.list[grp][0];
+
+  Staged st;
+  st.q0 = st.q1 = st.q2 = make_float4(0.f, 0.f, 0.f, 0.f);
+  st.kk = st.isyy = 0.0f;
+  st.rect_min = st.rect_wh = st.slot_base = 0;
+  // unconditional, index-clamped staging loads (see the forward kernel): ids two rounds ahead,
+  // records one round ahead, walking the list back to front
+  auto load_id = [&](uint32_t lo, uint32_t top) { return point_list[start + min(lo + lane, top - 1)]; };
+  auto load_rec = [&](uint32_t id) {
+    load_staged<true>(rec, id, st);          // q2.w = tile_mask
+    st.slot_base = slot_base[id];
+    const uint2 rr = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(rec + id) + 48);
+    st.rect_min = rr.x;
+    st.rect_wh = rr.y;
+  };
+  uint32_t lo = hi > BATCH ? hi - BATCH : 0u;
+  uint32_t id_next = 0;
+  if (hi > 0) {
+    load_rec(load_id(lo, hi));
+    const uint32_t lo2 = lo > BATCH ? lo - BATCH : 0u;
+    id_next = load_id(lo2, max(lo, 1u));
+  }
+
+  while (hi > 0) {
+    const uint32_t cur_lo = lo;
+    const bool have = lo + lane < hi;
+    // sub-blocks that still have a contributor in this round (1-based indices cur_lo + 1 .. hi)
+    const uint32_t active = (sub_last[0] > cur_lo ? 1u : 0u) | (sub_last[1] > cur_lo ? 2u : 0u) |
+                            (sub_last[2] > cur_lo ? 4u : 0u) | (sub_last[3] > cur_lo ? 8u : 0u);
+    const uint32_t m = (have ? subblock_mask(st.q0.x, st.q0.y, st.q2.y, st.q2.z, st.q0.z, st.q0.w, st.q1.x, st.q1.y, tx0, ty0) : 0u) & active;
+    // the 0.99 clamp can only be reached by an opacity above it (to the ulp of v_log / v_exp)
+    const bool clamp = __builtin_amdgcn_ballot_w64(m != 0u && st.q1.y > ALPHA_MAX) != 0ull;
+    // gradient-row slot of this instance: the Gaussian's first slot + the rank of this tile among its instances
+    const uint32_t rw = st.rect_wh & 0xffffu;
+    const uint32_t bit = ((uint32_t)tile_y - rect_min_y(st.rect_min)) * rw + ((uint32_t)tile_x - rect_min_x(st.rect_min));
+    const uint32_t slot = st.slot_base + bin_rank(st.rect_wh, __float_as_uint(st.q2.w), have ? bit : 0u);
+    LdsRec lr;
+    make_lds(st, lr);
+    const float lo2op = lr.B.y;                      // log2(opacity): 1 / opacity for the row at the end of the round
+    __builtin_amdgcn_wave_barrier();
+    L.A[lane] = lr.A;
+    L.B[lane] = lr.B;
+    L.C[lane] = st.q2.x;
+    {   // zero the slab, pad the lists
+      float4* z = reinterpret_cast<float4*>(L.slab);
+#pragma unroll
+      for (int t = 0; t < SB_SLAB * 8 / (16 * WAVE); ++t) z[t * WAVE + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const uint32_t dd = 16u * SB_DUMMY * 0x10001u;
+      uint4* l4 = reinterpret_cast<uint4*>(&L.list[0][0]);
+      if (lane < 4 * SB_LIST * 2 / 16) l4[lane] = make_uint4(dd, dd, dd, dd);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // lists back to front: the highest lane (latest list position) first
+    uint32_t nmax = 0;
+    const unsigned long long above = ~((2ull << lane) - 1ull);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool mine = (m >> k) & 1u;
+      const unsigned long long bal = __builtin_amdgcn_ballot_w64(mine);
+      nmax = max(nmax, (uint32_t)__popcll(bal));
+      if (mine) L.list[k][__popcll(bal & above)] = (uint16_t)(16 * lane);
+    }
+    hi = lo;
+    lo = hi > BATCH ? hi - BATCH : 0u;
+    {   // prefetch: record of the next (earlier) round, ids of the one after it
+      load_rec(id_next);
+      const uint32_t lo2 = lo > BATCH ? lo - BATCH : 0u;
+      id_next = load_id(lo2, max(lo, 1u));
+    }
+    __builtin_amdgcn_wave_barrier();
+    // steps at which two of the four lists hold the same instance (lane i looks at step i): those add to the slab one
+    // group after the other
+    unsigned long long clash;
+    {
+      const uint32_t a = L.list[0][lane], b = L.list[1][lane], c = L.list[2][lane], d = L.list[3][lane];
+      const uint32_t dm = 16u * SB_DUMMY;
+      clash = __builtin_amdgcn_ballot_w64((a != dm && (a == b || a == c || a == d)) || (b != dm && (b == c || b == d)) ||
+                                          (c != dm && c == d));
+    }
+    uint32_t e0 = mylist[0];
+    for (uint32_t i = 0; i < nmax; ++i) {
+      const uint32_t e1 = mylist[i + 1];
+      const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(L.A) + e0);
+      const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(L.B) + e0);
+      const float cb = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(L.C) + (e0 >> 2));
+      const uint32_t pos1 = cur_lo + (e0 >> 4) + 1u;
+      // per-lane partial sums over the quad; un-scaled forms (constants applied to the row):
+      //   v0 = sum h dx, v1 = sum h dy (first moments), v2 = sum h dx^2, v3 = sum h dx dy, v4 = sum h dy^2 with
+      //   h = opacity*G*dL_dalpha;  v5 = sum h (= opacity * dL_dopacity);  v6..8 = sum alpha*T*dL_dpix
+      float v[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool live = pos1 <= last[k];
+        if (__builtin_amdgcn_ballot_w64(live) == 0ull) continue;      // every pixel of this quad position is past its last contributor
+        const float dx = a.x - ((k & 1) ? pxf1 : pxf0), dy = a.y - ((k >> 1) ? pyf1 : pyf0);
+        const float ar = __builtin_amdgcn_exp2f(pair_p2(dx, dy, a.z, a.w, b.x, b.y));      // opacity * G
+        const float alpha = clamp ? fminf(ALPHA_MAX, ar) : ar;
+        const bool ok = live && (alpha >= ALPHA_MIN);
+        // lanes that do not contribute run the same instructions on alpha = 0: 1 / (1 - 0) = 1 and every product is 0
+        const float am = ok ? alpha : 0.0f, arm = ok ? ar : 0.0f;
+        const float rcp = __builtin_amdgcn_rcpf(1.0f - am);
+        T[k] *= rcp;                                   // transmittance in front of this instance
+        const float cd = fmaf(cb, dpb[k], fmaf(b.w, dpg[k], b.z * dpr[k]));   // c . dL_dpix
+        const float dch = am * T[k];
+        const float dL_dalpha = fmaf(T[k], cd, -Bk[k] * rcp);
+        Bk[k] = fmaf(cd, dch, Bk[k]);
+        const float h = arm * dL_dalpha;               // opacity * G * dL_dalpha: the clamp passes the gradient on
+        const float hx = h * dx, hy = h * dy;
+        v[0] += hx; v[1] += hy;
+        v[2] = fmaf(hx, dx, v[2]); v[3] = fmaf(hx, dy, v[3]); v[4] = fmaf(hy, dy, v[4]);
+        v[5] += h;
+        v[6] = fmaf(dch, dpr[k], v[6]); v[7] = fmaf(dch, dpg[k], v[7]); v[8] = fmaf(dch, dpb[k], v[8]);
+      }
+      float n0, n1, n2;
+      row_fold9(v, n0, n1, n2);
+      // lane j of bank k takes the bank's value of n0 (j = 0), n1 (j = 1), n2 (j = 2, bank 0 only): the nine sums of the
+      // row sit in nine lanes and go to the slab with one read-add-write (LDS float atomics retire about one lane per
+      // cycle per CU: far slower)
+      const float nn = (sel == 0) ? n0 : (sel == 1 ? n1 : n2);
+      double* dst = L.slab + 9 * (e0 >> 4) + (acc_lane < 0 ? 0 : acc_lane);
+      const bool adds = acc_lane >= 0;
+      if (!((clash >> i) & 1ull)) {
+        if (adds) *dst += (double)nn;
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (adds && grp == g) *dst += (double)nn;
+          __builtin_amdgcn_wave_barrier();     // LDS operations of one wave execute in order
+        }
+      }
+      e0 = e1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // one row per staged instance that received anything (all-zero sums: no row, the flag byte stays 0)
+    if (m != 0u) {
+      const double* s9 = L.slab + 9 * lane;
+      float r9[9];
+      bool nz = false;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) { r9[t] = (float)s9[t]; nz = nz || r9[t] != 0.0f; }
+      if (nz) {
+        float4* dst = reinterpret_cast<float4*>(rows + slot);
+        dst[0] = make_float4(r9[0], r9[1], -0.5f * r9[2], -r9[3]);                                   // Mx, My, dcxx, dcxy
+        dst[1] = make_float4(-0.5f * r9[4], r9[5] * __builtin_amdgcn_exp2f(-lo2op), r9[6], r9[7]);   // dcyy, dop, dr, dg
+        dst[2] = make_float4(r9[8], 0.f, 0.f, 0.f);                                                  // db
+        row_flags[slot] = 1;
+      }
+    }
+  }
+}
+
+#ifndef BWD_WAVES
+#define BWD_WAVES 4
+#endif
+__global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE, BWD_WAVES) void render_bwd_kernel(int W, int H, int grid_x, int num_tiles,
                                                           const uint32_t* __restrict__ tile_order,
                                                           const uint2* __restrict__ ranges,
                                                           const uint32_t* __restrict__ point_list,
@@ -612,16 +876,25 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE, 6) void render_bwd_kernel(i
                                                           const float* __restrict__ dL_dpix,
                                                           GradRow* __restrict__ rows,
                                                           uint8_t* __restrict__ row_flags) {
+#if !defined(GSR_BWD_CLASSIC)
+  __shared__ SbLds sL[WAVES_PER_BLOCK];
+#else
   __shared__ float4 sA[WAVES_PER_BLOCK][BATCH];
   __shared__ float4 sB[WAVES_PER_BLOCK][BATCH];
   __shared__ float sC[WAVES_PER_BLOCK][BATCH];
+#endif
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
   const int slot = blockIdx.x * WAVES_PER_BLOCK + wid;
   if (slot >= num_tiles) return;
   const int tile = __builtin_amdgcn_readfirstlane((int)tile_order[slot]);
+#if !defined(GSR_BWD_CLASSIC)
+  render_bwd_tile_sb16(tile, sL[wid], W, H, grid_x, ranges, point_list, rec, slot_base, bg, final_T, n_contrib, tile_max,
+                       dL_dpix, rows, row_flags);
+#else
   render_bwd_tile(tile, sA[wid], sB[wid], sC[wid], W, H, grid_x, ranges, point_list, rec, slot_base, bg, final_T, n_contrib,
                   tile_max, dL_dpix,
                   rows, row_flags);
+#endif
 }
 
 void launch_render_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
