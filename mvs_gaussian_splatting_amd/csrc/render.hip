@@ -18,6 +18,7 @@
 // permlane swaps) and written as one row per (Gaussian, tile) instance -- no atomics; preprocess_bwd sums the rows.
 #include "gsr_common.h"
 #include "gsr_launch.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace gsr {
@@ -788,59 +789,64 @@ __device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, i
       clash = __builtin_amdgcn_ballot_w64((a != dm && (a == b || a == c || a == d)) || (b != dm && (b == c || b == d)) ||
                                           (c != dm && c == d));
     }
-    uint32_t e0 = mylist[0];
-    for (uint32_t i = 0; i < nmax; ++i) {
-      const uint32_t e1 = mylist[i + 1];
-      const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(L.A) + e0);
-      const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(L.B) + e0);
-      const float cb = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(L.C) + (e0 >> 2));
-      const uint32_t pos1 = cur_lo + (e0 >> 4) + 1u;
-      // per-lane partial sums over the quad; un-scaled forms (constants applied to the row):
-      //   v0 = sum h dx, v1 = sum h dy (first moments), v2 = sum h dx^2, v3 = sum h dx dy, v4 = sum h dy^2 with
-      //   h = opacity*G*dL_dalpha;  v5 = sum h (= opacity * dL_dopacity);  v6..8 = sum alpha*T*dL_dpix
-      float v[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const bool live = pos1 <= last[k];
-        if (__builtin_amdgcn_ballot_w64(live) == 0ull) continue;      // every pixel of this quad position is past its last contributor
-        const float dx = a.x - ((k & 1) ? pxf1 : pxf0), dy = a.y - ((k >> 1) ? pyf1 : pyf0);
-        const float ar = __builtin_amdgcn_exp2f(pair_p2(dx, dy, a.z, a.w, b.x, b.y));      // opacity * G
-        const float alpha = clamp ? fminf(ALPHA_MAX, ar) : ar;
-        const bool ok = live && (alpha >= ALPHA_MIN);
-        // lanes that do not contribute run the same instructions on alpha = 0: 1 / (1 - 0) = 1 and every product is 0
-        const float am = ok ? alpha : 0.0f, arm = ok ? ar : 0.0f;
-        const float rcp = __builtin_amdgcn_rcpf(1.0f - am);
-        T[k] *= rcp;                                   // transmittance in front of this instance
-        const float cd = fmaf(cb, dpb[k], fmaf(b.w, dpg[k], b.z * dpr[k]));   // c . dL_dpix
-        const float dch = am * T[k];
-        const float dL_dalpha = fmaf(T[k], cd, -Bk[k] * rcp);
-        Bk[k] = fmaf(cd, dch, Bk[k]);
-        const float h = arm * dL_dalpha;               // opacity * G * dL_dalpha: the clamp passes the gradient on
-        const float hx = h * dx, hy = h * dy;
-        v[0] += hx; v[1] += hy;
-        v[2] = fmaf(hx, dx, v[2]); v[3] = fmaf(hx, dy, v[3]); v[4] = fmaf(hy, dy, v[4]);
-        v[5] += h;
-        v[6] = fmaf(dch, dpr[k], v[6]); v[7] = fmaf(dch, dpg[k], v[7]); v[8] = fmaf(dch, dpb[k], v[8]);
-      }
-      float n0, n1, n2;
-      row_fold9(v, n0, n1, n2);
-      // lane j of bank k takes the bank's value of n0 (j = 0), n1 (j = 1), n2 (j = 2, bank 0 only): the nine sums of the
-      // row sit in nine lanes and go to the slab with one read-add-write (LDS float atomics retire about one lane per
-      // cycle per CU: far slower)
-      const float nn = (sel == 0) ? n0 : (sel == 1 ? n1 : n2);
-      double* dst = L.slab + 9 * (e0 >> 4) + (acc_lane < 0 ? 0 : acc_lane);
-      const bool adds = acc_lane >= 0;
-      if (!((clash >> i) & 1ull)) {
-        if (adds) *dst += (double)nn;
-      } else {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          if (adds && grp == g) *dst += (double)nn;
-          __builtin_amdgcn_wave_barrier();     // LDS operations of one wave execute in order
+    // two copies of the walk: the 0.99 clamp costs an instruction per pixel and almost no round needs it
+    auto walk = [&](auto clamped_c) {
+      constexpr bool CLAMPED = decltype(clamped_c)::value;
+      uint32_t e0 = mylist[0];
+      for (uint32_t i = 0; i < nmax; ++i) {
+        const uint32_t e1 = mylist[i + 1];
+        const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(L.A) + e0);
+        const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(L.B) + e0);
+        const float cb = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(L.C) + (e0 >> 2));
+        const uint32_t pos1 = cur_lo + (e0 >> 4) + 1u;
+        // per-lane partial sums over the quad; un-scaled forms (constants applied to the row):
+        //   v0 = sum h dx, v1 = sum h dy (first moments), v2 = sum h dx^2, v3 = sum h dx dy, v4 = sum h dy^2 with
+        //   h = opacity*G*dL_dalpha;  v5 = sum h (= opacity * dL_dopacity);  v6..8 = sum alpha*T*dL_dpix
+        float v[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bool live = pos1 <= last[k];
+          if (__builtin_amdgcn_ballot_w64(live) == 0ull) continue;      // every pixel of this quad position is past its last contributor
+          const float dx = a.x - ((k & 1) ? pxf1 : pxf0), dy = a.y - ((k >> 1) ? pyf1 : pyf0);
+          const float ar = __builtin_amdgcn_exp2f(pair_p2(dx, dy, a.z, a.w, b.x, b.y));      // opacity * G
+          const bool ok = live && (ar >= ALPHA_MIN);        // (the clamp is above the threshold: same test on either)
+          // lanes that do not contribute run the same instructions on alpha = 0: 1 / (1 - 0) = 1 and every product is 0
+          const float arm = ok ? ar : 0.0f;
+          const float am = CLAMPED ? fminf(ALPHA_MAX, arm) : arm;
+          const float rcp = __builtin_amdgcn_rcpf(1.0f - am);
+          T[k] *= rcp;                                   // transmittance in front of this instance
+          const float cd = fmaf(cb, dpb[k], fmaf(b.w, dpg[k], b.z * dpr[k]));   // c . dL_dpix
+          const float dch = am * T[k];
+          const float dL_dalpha = fmaf(T[k], cd, -Bk[k] * rcp);
+          Bk[k] = fmaf(cd, dch, Bk[k]);
+          const float h = arm * dL_dalpha;               // opacity * G * dL_dalpha: the clamp passes the gradient on
+          const float hx = h * dx, hy = h * dy;
+          v[0] += hx; v[1] += hy;
+          v[2] = fmaf(hx, dx, v[2]); v[3] = fmaf(hx, dy, v[3]); v[4] = fmaf(hy, dy, v[4]);
+          v[5] += h;
+          v[6] = fmaf(dch, dpr[k], v[6]); v[7] = fmaf(dch, dpg[k], v[7]); v[8] = fmaf(dch, dpb[k], v[8]);
         }
+        float n0, n1, n2;
+        row_fold9(v, n0, n1, n2);
+        // lane j of bank k takes the bank's value of n0 (j = 0), n1 (j = 1), n2 (j = 2, bank 0 only): the nine sums of the
+        // row sit in nine lanes and go to the slab with one read-add-write (LDS float atomics retire about one lane per
+        // cycle per CU: far slower)
+        const float nn = (sel == 0) ? n0 : (sel == 1 ? n1 : n2);
+        double* dst = L.slab + 9 * (e0 >> 4) + (acc_lane < 0 ? 0 : acc_lane);
+        const bool adds = acc_lane >= 0;
+        if (!((clash >> i) & 1ull)) {
+          if (adds) *dst += (double)nn;
+        } else {
+  #pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            if (adds && grp == g) *dst += (double)nn;
+            __builtin_amdgcn_wave_barrier();     // LDS operations of one wave execute in order
+          }
+        }
+        e0 = e1;
       }
-      e0 = e1;
-    }
+    };
+    if (clamp) walk(std::true_type{}); else walk(std::false_type{});
     __builtin_amdgcn_wave_barrier();
     // one row per staged instance that received anything (all-zero sums: no row, the flag byte stays 0)
     if (m != 0u) {
