@@ -803,6 +803,7 @@ __device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, i
         //   v0 = sum h dx, v1 = sum h dy (first moments), v2 = sum h dx^2, v3 = sum h dx dy, v4 = sum h dy^2 with
         //   h = opacity*G*dL_dalpha;  v5 = sum h (= opacity * dL_dopacity);  v6..8 = sum alpha*T*dL_dpix
         float v[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float S = 0.f, Sx = 0.f, Sy = 0.f, Sxy = 0.f;
   #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const bool live = pos1 <= last[k];
@@ -820,11 +821,22 @@ __device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, i
           const float dL_dalpha = fmaf(T[k], cd, -Bk[k] * rcp);
           Bk[k] = fmaf(cd, dch, Bk[k]);
           const float h = arm * dL_dalpha;               // opacity * G * dL_dalpha: the clamp passes the gradient on
-          const float hx = h * dx, hy = h * dy;
-          v[0] += hx; v[1] += hy;
-          v[2] = fmaf(hx, dx, v[2]); v[3] = fmaf(hx, dy, v[3]); v[4] = fmaf(hy, dy, v[4]);
-          v[5] += h;
+          // moments of h about the quad's first pixel: the offsets of the other three are 0 / 1, so h itself is all that
+          // is added per pixel (dx_k = dx_0 - (k & 1) and dy_k = dy_0 - (k >> 1) exactly: all four differences are exact)
+          S += h;
+          if (k & 1) Sx += h;
+          if (k >> 1) Sy += h;
+          if (k == 3) Sxy = h;
           v[6] = fmaf(dch, dpr[k], v[6]); v[7] = fmaf(dch, dpg[k], v[7]); v[8] = fmaf(dch, dpb[k], v[8]);
+        }
+        {   // sum h dx = dx0 S - Sx, sum h dx^2 = dx0 (dx0 S - 2 Sx) + Sx, sum h dx dy = dx0 (dy0 S - Sy) - dy0 Sx + Sxy, ...
+          const float dx0 = a.x - pxf0, dy0 = a.y - pyf0;
+          v[0] = fmaf(dx0, S, -Sx);
+          v[1] = fmaf(dy0, S, -Sy);
+          v[2] = fmaf(dx0, v[0] - Sx, Sx);
+          v[4] = fmaf(dy0, v[1] - Sy, Sy);
+          v[3] = fmaf(dx0, v[1], fmaf(-dy0, Sx, Sxy));
+          v[5] = S;
         }
         float n0, n1, n2;
         row_fold9(v, n0, n1, n2);
