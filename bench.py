@@ -333,7 +333,8 @@ def main():
         pipe.fuse_activations = True
 
     # instances of this rank's view: read back from the stage the operator itself ran
-    R = int(getattr(pkg["render"].grad_fn, "num_rendered", 0)) if pkg["render"].grad_fn is not None else 0
+    from mvs_gaussian_splatting_amd.rasterizer import frame_counts
+    R = int(frame_counts(pkg["render"])[0]) if pkg["render"].grad_fn is not None else 0
 
     if rank == 0:
         tiles = ((W + 15) // 16) * ((H + 15) // 16)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 10
+#define GSR_ABI_VERSION 11
 
 enum {
   GSR_OK = 0,
@@ -78,7 +78,13 @@ typedef struct GsrParams {
   int32_t forward_only;        /* 1: no gsr_backward will follow (inference): the compositing kernel does not track the
                                   last contributor and the per-pixel / per-Gaussian state the backward reads (final
                                   transmittance, contributor counts, gradient-row slots) is not written.  Same image. */
+  int32_t debug_flags;         /* GSR_DEBUG_* bits: switches the tests use (never read from the environment) */
 } GsrParams;
+
+enum {
+  GSR_DEBUG_NO_MINIBLOCK_CULL = 1  /* forward compositing: every staged instance enters all 16 mini-block lists (the
+                                      image must not change by a bit: tests/test_gpu_miniblock_cull.py) */
+};
 
 enum {
   GSR_BINNING_TWO_LEVEL = 0,   /* depth-sort the visible Gaussians (u32 keys), emit instances in depth order, stable
@@ -113,6 +119,14 @@ typedef struct GsrGrads {
   float* dL_drotations; /* device [P,4] */
   float* dL_dcov3D;     /* device [P,6] */
   float* dL_dshs_rest;  /* device [P,M-1,3]; required with shs_rest (dL_dshs is then [P,1,3]) */
+  /* Fused densification statistics (scene/gaussian_model.py:775-777 + train.py:130): all three
+   * NULL, or all three set -- then the per-Gaussian backward kernel, which holds dL_dmeans2D and the radius in
+   * registers, also does  xyz_gradient_accum[i] += ||dL_dmeans2D[i].xy||, denom[i] += 1,
+   * max_radii2D[i] = max(max_radii2D[i], radii[i])  for every Gaussian with radii[i] > 0 (same arithmetic as
+   * gsr_densify_stats, which stays available as the stand-alone step). */
+  float* stats_xyz_gradient_accum; /* device [P] (the reference keeps [P,1]) */
+  float* stats_denom;              /* device [P] */
+  float* stats_max_radii2D;        /* device [P] */
 } GsrGrads;
 
 /* ---- introspection ------------------------------------------------------------------ */
@@ -139,6 +153,27 @@ int gsr_forward_preprocess(const GsrParams* p, void* geom_ws, int32_t* radii, vo
 int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t bin_ws_bytes,
                        void* img_ws, uint32_t num_rendered, uint32_t num_visible, float* out_color, void* stream);
 
+/* Both stages in one call with NO host synchronisation (SURVEY §7 "hard parts": caller-provided capacity + overflow
+ * flag instead of upstream's per-forward num_rendered read-back, gaussian_renderer/__init__.py:257-265).
+ *   capacity     : instances the binning workspace can hold; bin_ws must hold
+ *                  gsr_binning_bytes(capacity, P, W, H, mode) bytes.  Every launch is sized for (capacity, P) and the
+ *                  kernels take the real counts from device memory.
+ *   p->counts_pinned (required): receives (num_rendered, num_visible, min depth key, max depth key) when the scan
+ *                  kernel has run; `counts_event` (a handle from gsr_event_create, or NULL) is recorded right behind it.
+ *   Overflow     : when num_rendered > capacity the instances past the capacity are dropped (no out-of-bounds
+ *                  access, but the image and every gradient of the frame are INCOMPLETE): the caller must compare
+ *                  counts_pinned[0] with its capacity once the event has completed and discard / redo the frame.
+ *   Backward     : call gsr_backward with num_rendered = capacity and num_visible = P (the values the workspaces
+ *                  were laid out with); gsr_backward_bytes(P, capacity) sizes its workspace.
+ * Only GSR_BINNING_TWO_LEVEL / _CULLED (the 64-bit key mode keeps the two-call path). */
+int gsr_forward(const GsrParams* p, void* geom_ws, void* bin_ws, size_t bin_ws_bytes, uint32_t capacity, void* img_ws,
+                int32_t* radii, float* out_color, void* counts_event, void* stream);
+/* events for the deferred count check (plain HIP events without timing; usable from any thread) */
+int gsr_event_create(void** event);
+int gsr_event_destroy(void* event);
+int gsr_event_wait(void* event);                 /* blocks the calling thread until the event has completed */
+int gsr_event_query(void* event, int32_t* done); /* *done = 1 when completed; never blocks */
+
 /* ---- backward ------------------------------------------------------------------------- */
 int gsr_backward(const GsrParams* p, const int32_t* radii, const void* geom_ws, const void* bin_ws,
                  const void* img_ws, uint32_t num_rendered, uint32_t num_visible,
@@ -160,7 +195,9 @@ int gsr_debug_read_geom(const void* geom_ws, int32_t P, float* xy /*[P,2]*/, flo
                         float* rgb /*[P,3]*/, float* depth /*[P]*/, uint32_t* tiles_touched /*[P]*/,
                         uint32_t* point_offsets /*[P]*/, uint32_t* rect /*[P,4] x0,y0,x1,y1*/,
                         uint32_t* clamped /*[P]*/, void* stream);
-/* keys_sorted are the (tile<<32|depth) keys of the sorted instances (rebuilt from the result in two-level mode) */
+/* keys_sorted are the (tile<<32|depth) keys of the sorted instances (rebuilt from the result in two-level mode).
+ * (num_rendered, num_visible) = what the binning workspace was laid out for: after gsr_forward that is (capacity, P),
+ * and only the first real-count entries of the outputs are meaningful. */
 int gsr_debug_read_binning(const void* geom_ws, int32_t P, const void* bin_ws, uint32_t num_rendered,
                            uint32_t num_visible, int32_t width, int32_t height, int32_t binning_mode,
                            uint64_t* keys_sorted, uint32_t* point_list, void* stream);
@@ -185,6 +222,10 @@ int gsr_profile_destroy(void* handle);
  * recorded intervals into counts[GSR_STAGE_COUNT], then clears the handle for reuse */
 int gsr_profile_collect(void* handle, double* ms_sum, uint32_t* counts);
 const char* gsr_stage_name(int32_t stage);
+/* roctx ranges ("gsr:<stage>") around the same stages, for rocprofv3 --marker-trace.  Off by default;
+ * on = 1 loads librocprofiler-sdk-roctx.so (or libroctx64.so) at run time and returns GSR_E_BADARG if neither is
+ * there.  Process-wide switch, safe to call from any thread. */
+int gsr_enable_markers(int32_t on);
 
 /* ---- caller-side steps of the train loop ---------------------------- */
 /* L1 loss (utils/loss_utils.py:17-18) forward + gradient in one pass:

@@ -10,9 +10,11 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
+# GSR_LIB_PATH (read once, at import): lets the A/B tuning tools (tools/ab_*.sh) point the binding at a candidate build
+# instead of copying it over the in-tree library
+LIB_PATH = os.environ.get("GSR_LIB_PATH") or os.path.join(_HERE, "libgsr_hip.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class GsrParams(C.Structure):
@@ -26,7 +28,7 @@ class GsrParams(C.Structure):
         ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
         ("campos", C.c_void_p), ("bg", C.c_void_p), ("profile", C.c_void_p),
         ("shs_rest", C.c_void_p), ("act_flags", C.c_int32), ("binning_mode", C.c_int32),
-        ("counts_pinned", C.c_void_p), ("forward_only", C.c_int32),
+        ("counts_pinned", C.c_void_p), ("forward_only", C.c_int32), ("debug_flags", C.c_int32),
     ]
 
 
@@ -35,11 +37,13 @@ class GsrGrads(C.Structure):
         ("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
         ("dL_dcolors", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
         ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p), ("dL_dshs_rest", C.c_void_p),
+        ("stats_xyz_gradient_accum", C.c_void_p), ("stats_denom", C.c_void_p), ("stats_max_radii2D", C.c_void_p),
     ]
 
 ACT_SCALE_EXP, ACT_ROT_NORMALIZE, ACT_OPACITY_SIGMOID = 1, 2, 4
 BINNING_TWO_LEVEL, BINNING_KEYS64, BINNING_TWO_LEVEL_CULLED = 0, 1, 2
 DSSIM_ONE_MINUS_MEAN, DSSIM_CLAMPED_HALF = 0, 1
+DEBUG_NO_MINIBLOCK_CULL = 1
 
 
 # name -> (restype, argtypes); every symbol include/gsr.h declares
@@ -55,6 +59,13 @@ SYMBOLS = {
                                          C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "gsr_forward_render": (C.c_int, [C.POINTER(GsrParams), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                      C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "gsr_forward": (C.c_int, [C.POINTER(GsrParams), C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gsr_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "gsr_event_destroy": (C.c_int, [C.c_void_p]),
+    "gsr_event_wait": (C.c_int, [C.c_void_p]),
+    "gsr_event_query": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "gsr_enable_markers": (C.c_int, [C.c_int32]),
     "gsr_backward": (C.c_int, [C.POINTER(GsrParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(GsrGrads), C.c_void_p]),
     "gsr_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -127,6 +138,11 @@ def load() -> C.CDLL:
             raise GsrError(f"ABI mismatch: library {lib.gsr_abi_version()} != binding {ABI_VERSION}")
         _lib = lib
     return _lib
+
+
+def enable_markers(on: bool = True) -> None:
+    """roctx ranges ("gsr:<stage>") around every stage, for ``rocprofv3 --marker-trace``; off by default."""
+    check(load().gsr_enable_markers(1 if on else 0), "gsr_enable_markers")
 
 
 def check(rc: int, what: str) -> None:

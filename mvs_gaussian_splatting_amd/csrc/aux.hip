@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void densify_stats_kernel(int P, const float* 
   const int32_t r = radii[i];
   if (r > 0) {
     const float gx = dL_dmeans2D[3 * (size_t)i], gy = dL_dmeans2D[3 * (size_t)i + 1];
-    accum[i] += sqrtf(gx * gx + gy * gy);
+    accum[i] += densify_grad_norm(gx, gy);
     denom[i] += 1.0f;
     max_radii2D[i] = fmaxf(max_radii2D[i], (float)r);
   }

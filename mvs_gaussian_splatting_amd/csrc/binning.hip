@@ -94,10 +94,21 @@ __global__ __launch_bounds__(PRE_BLOCK) void compact_visible_kernel(int P, const
                                                                     const uint32_t* __restrict__ depth_inv_min,
                                                                     int grid_x,
                                                                     uint32_t* __restrict__ dkey,
-                                                                    uint2* __restrict__ dval) {
+                                                                    uint2* __restrict__ dval,
+                                                                    uint32_t* __restrict__ total, uint32_t capacity) {
   __shared__ uint32_t wave_tot[PRE_BLOCK / WAVE];
   __shared__ uint32_t wave_tiles[PRE_BLOCK / WAVE];
   const uint32_t min_bits = ~*depth_inv_min;      // smallest depth key of the frame: keys are sorted relative to it
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // counts the later stages read from the device (total = [R, V, big, -, ~min depth key, max depth key, ...]):
+    //   [6] elements of the depth sort's top-digit pass: V when the frame spans more than 2^DEPTH_SORT_BITS depth keys
+    //       (the pass then runs and the sorted payload ends in the other buffer), else 0 (its kernels exit at once)
+    //   [7] instances the binning workspace really receives: min(R, capacity)
+    const uint32_t R = total[TOTAL_R], V = total[TOTAL_V], mx = total[TOTAL_DEPTH_MAX];
+    const bool top = V > 0u && mx >= min_bits && ((mx - min_bits) >> DEPTH_SORT_BITS) != 0u;
+    total[TOTAL_TOP_PASS_N] = top ? V : 0u;
+    total[TOTAL_R_CLAMPED] = min(R, capacity);
+  }
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
   const int idx = blockIdx.x * PRE_BLOCK + tid;
   BinInfo bi{0u, 0u, 0.0f, 0u};
@@ -134,10 +145,16 @@ __device__ inline uint32_t sorted_tiles(uint2 v, const BinInfo* __restrict__ bin
   return (uint32_t)__popc(v.y >> PACK_MASK_SHIFT);
 }
 
-__global__ __launch_bounds__(PRE_BLOCK) void count_tiles_kernel(uint32_t V, const uint2* __restrict__ dval,
+// The depth-sorted payload lives in `d3` after the three regular passes and in `d4` when the top-digit pass ran
+// (total[TOTAL_TOP_PASS_N] != 0); V is read from the device (the grid may be sized for a capacity).
+__global__ __launch_bounds__(PRE_BLOCK) void count_tiles_kernel(const uint32_t* __restrict__ total,
+                                                                const uint2* __restrict__ d3,
+                                                                const uint2* __restrict__ d4,
                                                                 const BinInfo* __restrict__ bin,
                                                                 uint32_t* __restrict__ block_sums2) {
   __shared__ uint32_t wave_tot[PRE_BLOCK / WAVE];
+  const uint32_t V = total[TOTAL_V];
+  const uint2* __restrict__ dval = total[TOTAL_TOP_PASS_N] ? d4 : d3;
   const uint32_t i = blockIdx.x * PRE_BLOCK + threadIdx.x;
   const uint32_t t = i < V ? sorted_tiles(dval[i], bin) : 0u;
   const uint32_t ws = wave_reduce_add_u32(t);
@@ -155,12 +172,16 @@ __global__ __launch_bounds__(PRE_BLOCK) void count_tiles_kernel(uint32_t V, cons
 // takes output slots (not Gaussians), finds the owning Gaussian by binary search in the block's inclusive scan
 // (LDS) and derives the tile from the slot's rank inside the rect -- fully coalesced stores, no divergence on
 // the splat size (a per-Gaussian loop here ran at 0.5 TB/s).
-__global__ __launch_bounds__(PRE_BLOCK) void emit_instances_kernel(uint32_t V, int grid_x,
-                                                                   const uint2* __restrict__ dval,
+__global__ __launch_bounds__(PRE_BLOCK) void emit_instances_kernel(const uint32_t* __restrict__ total, int grid_x,
+                                                                   const uint2* __restrict__ d3,
+                                                                   const uint2* __restrict__ d4,
                                                                    const BinInfo* __restrict__ bin,
                                                                    const uint32_t* __restrict__ block_offs2,
                                                                    uint32_t* __restrict__ inst_tile,
-                                                                   uint32_t* __restrict__ inst_g) {
+                                                                   uint32_t* __restrict__ inst_g, uint32_t capacity) {
+  const uint32_t V = total[TOTAL_V];
+  if (blockIdx.x * PRE_BLOCK >= V) return;      // grid sized for a capacity (uniform exit: no barrier crossed)
+  const uint2* __restrict__ dval = total[TOTAL_TOP_PASS_N] ? d4 : d3;
   __shared__ uint32_t wave_tot[PRE_BLOCK / WAVE];
   __shared__ uint32_t s_incl[PRE_BLOCK];      // inclusive scan of tiles within the block
   __shared__ uint32_t s_g[PRE_BLOCK];
@@ -196,9 +217,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void emit_instances_kernel(uint32_t V, i
   s_wh[tid] = rr.y;
   s_mask[tid] = mask;
   __syncthreads();
-  const uint32_t total = s_incl[PRE_BLOCK - 1];
+  const uint32_t n_out = s_incl[PRE_BLOCK - 1];
   const uint32_t base = block_offs2[blockIdx.x];
-  for (uint32_t o = (uint32_t)tid; o < total; o += PRE_BLOCK) {
+  for (uint32_t o = (uint32_t)tid; o < n_out; o += PRE_BLOCK) {
     // smallest j with s_incl[j] > o
     int lo = 0, hi = PRE_BLOCK - 1;
 #pragma unroll
@@ -214,18 +235,24 @@ __global__ __launch_bounds__(PRE_BLOCK) void emit_instances_kernel(uint32_t V, i
     uint32_t q = (uint32_t)(((float)k + 0.5f) * (1.0f / (float)w));   // k / w (exact for k < 2^20)
     const uint32_t mn = s_min[j];
     const uint32_t x = (mn & 0xffffu) + (k - q * w), y = (mn >> 16) + q;
-    inst_tile[base + o] = y * (uint32_t)grid_x + x;
-    inst_g[base + o] = s_g[j];
+    if (base + o < capacity) {      // an overflowing frame drops its tail (the caller sees num_rendered > capacity)
+      inst_tile[base + o] = y * (uint32_t)grid_x + x;
+      inst_g[base + o] = s_g[j];
+    }
   }
 }
 
 // debug: the 64-bit keys a (tile, depth) sort would have produced, rebuilt from the two-level result
-__global__ __launch_bounds__(256) void reconstruct_keys_kernel(uint32_t R, const uint32_t* __restrict__ tile_sorted,
+__global__ __launch_bounds__(256) void reconstruct_keys_kernel(uint32_t R, uint32_t P,
+                                                               const uint32_t* __restrict__ tile_sorted,
                                                                const uint32_t* __restrict__ point_list,
                                                                const BinInfo* __restrict__ bin,
                                                                uint64_t* __restrict__ keys) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i < R) keys[i] = ((uint64_t)tile_sorted[i] << 32) | (uint64_t)__float_as_uint(bin[point_list[i]].depth);
+  if (i >= R) return;
+  // R may be the capacity of a gsr_forward frame: entries past the real count are uninitialised, never dereferenced
+  const uint32_t g = point_list[i];
+  keys[i] = g < P ? ((uint64_t)tile_sorted[i] << 32) | (uint64_t)__float_as_uint(bin[g].depth) : ~0ull;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -248,6 +275,9 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT* __
   constexpr int RADIX = 1 << BITS;
   __shared__ uint32_t h[RADIX];
   if (n_dev) n = *n_dev;     // element count known only on the device (grid sized for the capacity)
+  if (blockIdx.x * (SORT_THREADS * ITEMS) >= n) return;   // block past the count (grid sized for a capacity; n == 0: a
+                                                           // predicated pass that does not run) -- rowscan and scatter skip
+                                                           // the same columns
   const int tid = threadIdx.x;
 #pragma unroll
   for (int d = tid; d < RADIX; d += SORT_THREADS) h[d] = 0;
@@ -272,11 +302,18 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT* __
 // one block per digit row; rounds of 2048 entries: every lane scans 8 contiguous entries in registers (two 16-byte
 // loads), the block scans the 256 lane sums, the lane writes its 8 prefixes back
 __global__ __launch_bounds__(256) void radix_rowscan_kernel(uint32_t* __restrict__ hist, uint32_t nblocks,
-                                                            uint32_t* __restrict__ totals) {
+                                                            uint32_t* __restrict__ totals,
+                                                            const uint32_t* __restrict__ n_dev) {
   constexpr uint32_t PER = 8;
   __shared__ uint32_t wave_tot[256 / WAVE];
+  const uint32_t stride = nblocks;
+  if (n_dev) {
+    const uint32_t n = *n_dev;
+    if (n == 0) return;
+    nblocks = min(nblocks, (n + SORT_TILE - 1) / SORT_TILE);   // columns past the device-side count are never written or read
+  }
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
-  uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
+  uint32_t* row = hist + (size_t)blockIdx.x * stride;
   uint32_t carry = 0;
   for (uint32_t b0 = 0; b0 < nblocks; b0 += 256 * PER) {
     const uint32_t lo = b0 + (uint32_t)tid * PER;
@@ -486,8 +523,10 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
 // The caller zero-fills `ranges` (empty tiles stay (0,0)).
 // ------------------------------------------------------------------------------------------
 template <typename KeyT, int TILE_SHIFT>
-__global__ __launch_bounds__(256) void identify_tile_ranges_kernel(uint32_t R, const KeyT* __restrict__ keys,
+__global__ __launch_bounds__(256) void identify_tile_ranges_kernel(uint32_t R, const uint32_t* __restrict__ r_dev,
+                                                                   const KeyT* __restrict__ keys,
                                                                    uint2* __restrict__ ranges) {
+  if (r_dev) R = *r_dev;      // instance count known only on the device (grid sized for the capacity)
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= R) return;
   const uint32_t cur = (uint32_t)(keys[i] >> TILE_SHIFT);
@@ -586,7 +625,7 @@ static void sort_pass(const KeyT* kin, const ValT* vin, KeyT* kout, ValT* vout, 
   (void)L;
   hipLaunchKernelGGL((radix_hist_kernel<KeyT, BITS, ITEMS>), dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, n, n_dev, shift,
                      mask, nblocks, hist);
-  hipLaunchKernelGGL(radix_rowscan_kernel, dim3(1 << BITS), dim3(256), 0, s, hist, nblocks, totals);
+  hipLaunchKernelGGL(radix_rowscan_kernel, dim3(1 << BITS), dim3(256), 0, s, hist, nblocks, totals, n_dev);
   hipLaunchKernelGGL((radix_scatter_kernel<KeyT, ValT, BITS, ITEMS>), dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, vin, kout,
                      vout, n, n_dev, shift, mask, nblocks, hist, totals);
 }
@@ -640,12 +679,12 @@ bool launch_sort_pairs_u32_v64(uint32_t* keys_a, uint2* vals_a, uint32_t* keys_b
 }
 
 void launch_compact_visible(int P, const BinInfo* bin, const uint32_t* block_vis_offs, const uint32_t* block_offs,
-                            uint32_t* slot_base, const uint32_t* depth_inv_min, int grid_x, uint32_t* dkey, uint2* dval,
-                            hipStream_t s) {
+                            uint32_t* slot_base, uint32_t* total, uint32_t capacity, int grid_x, uint32_t* dkey,
+                            uint2* dval, hipStream_t s) {
   const int nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
   if (nb > 0)
     hipLaunchKernelGGL(compact_visible_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, P, bin, block_vis_offs, block_offs, slot_base,
-                       depth_inv_min, grid_x, dkey, dval);
+                       total + TOTAL_DEPTH_INV_MIN, grid_x, dkey, dval, total, capacity);
 }
 // one more pass on bits [shift, shift + nbits) of 32-bit keys (nbits <= 8): the top digit of the depth sort
 void launch_sort_extra_pass_u32(const uint32_t* kin, const uint2* vin, uint32_t* kout, uint2* vout, uint32_t n,
@@ -656,20 +695,23 @@ void launch_sort_extra_pass_u32(const uint32_t* kin, const uint2* vin, uint32_t*
   uint32_t* totals = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + L.totals);
   sort_pass<uint32_t, uint2, 8>(kin, vin, kout, vout, n, n_dev, shift, nbits, L, hist, totals, s);
 }
-void launch_count_tiles(uint32_t V, const uint2* dval, const BinInfo* bin, uint32_t* block_sums2, hipStream_t s) {
-  const uint32_t nb = (V + PRE_BLOCK - 1) / PRE_BLOCK;
-  if (nb) hipLaunchKernelGGL(count_tiles_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, V, dval, bin, block_sums2);
+// v_cap: the number of visible Gaussians, or a capacity for it (the kernels read V from total[])
+void launch_count_tiles(uint32_t v_cap, const uint32_t* total, const uint2* d3, const uint2* d4, const BinInfo* bin,
+                        uint32_t* block_sums2, hipStream_t s) {
+  const uint32_t nb = (v_cap + PRE_BLOCK - 1) / PRE_BLOCK;
+  if (nb) hipLaunchKernelGGL(count_tiles_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, total, d3, d4, bin, block_sums2);
 }
-void launch_emit_instances(uint32_t V, int grid_x, const uint2* dval, const BinInfo* bin, const uint32_t* block_offs2,
-                           uint32_t* inst_tile, uint32_t* inst_g, hipStream_t s) {
-  const uint32_t nb = (V + PRE_BLOCK - 1) / PRE_BLOCK;
+void launch_emit_instances(uint32_t v_cap, const uint32_t* total, int grid_x, const uint2* d3, const uint2* d4,
+                           const BinInfo* bin, const uint32_t* block_offs2, uint32_t* inst_tile, uint32_t* inst_g,
+                           uint32_t capacity, hipStream_t s) {
+  const uint32_t nb = (v_cap + PRE_BLOCK - 1) / PRE_BLOCK;
   if (nb)
-    hipLaunchKernelGGL(emit_instances_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, V, grid_x, dval, bin, block_offs2, inst_tile,
-                       inst_g);
+    hipLaunchKernelGGL(emit_instances_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, total, grid_x, d3, d4, bin, block_offs2,
+                       inst_tile, inst_g, capacity);
 }
-void launch_reconstruct_keys(uint32_t R, const uint32_t* tile_sorted, const uint32_t* point_list, const BinInfo* bin,
-                             uint64_t* keys, hipStream_t s) {
-  if (R) hipLaunchKernelGGL(reconstruct_keys_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, tile_sorted, point_list, bin, keys);
+void launch_reconstruct_keys(uint32_t R, uint32_t P, const uint32_t* tile_sorted, const uint32_t* point_list,
+                             const BinInfo* bin, uint64_t* keys, hipStream_t s) {
+  if (R) hipLaunchKernelGGL(reconstruct_keys_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, P, tile_sorted, point_list, bin, keys);
 }
 
 void launch_build_tile_order(int tiles, const uint2* ranges, uint32_t* order, hipStream_t s) {
@@ -678,12 +720,13 @@ void launch_build_tile_order(int tiles, const uint2* ranges, uint32_t* order, hi
 
 void launch_identify_tile_ranges(uint32_t R, const uint64_t* keys, uint2* ranges, hipStream_t s) {
   if (R == 0) return;
-  hipLaunchKernelGGL((identify_tile_ranges_kernel<uint64_t, 32>), dim3((R + 255) / 256), dim3(256), 0, s, R, keys,
-                     ranges);
+  hipLaunchKernelGGL((identify_tile_ranges_kernel<uint64_t, 32>), dim3((R + 255) / 256), dim3(256), 0, s, R,
+                     (const uint32_t*)nullptr, keys, ranges);
 }
-void launch_identify_tile_ranges_u32(uint32_t R, const uint32_t* tiles, uint2* ranges, hipStream_t s) {
+void launch_identify_tile_ranges_u32(uint32_t R, const uint32_t* tiles, uint2* ranges, hipStream_t s,
+                                     const uint32_t* r_dev) {
   if (R == 0) return;
-  hipLaunchKernelGGL((identify_tile_ranges_kernel<uint32_t, 0>), dim3((R + 255) / 256), dim3(256), 0, s, R, tiles,
+  hipLaunchKernelGGL((identify_tile_ranges_kernel<uint32_t, 0>), dim3((R + 255) / 256), dim3(256), 0, s, R, r_dev, tiles,
                      ranges);
 }
 

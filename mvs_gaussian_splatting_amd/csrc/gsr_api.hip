@@ -1,8 +1,10 @@
 // extern "C" entry points of libgsr_hip.so (declared in include/gsr.h).  Host logic only:
 // argument validation, workspace carving, kernel sequencing on the caller's stream.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -95,22 +97,60 @@ struct Profile {
     used.push_back(sp);
   }
 };
-// an event that is destroyed on every exit path
-struct ScopedEvent {
+// The count read-back of the two-call forward waits on one event per frame: it is created once per (thread, device)
+// and lives as long as the thread (a fresh hipEventCreate / Destroy per frame cost ~10 us of host time).
+struct ThreadEvent {
+  int dev = -1;
   hipEvent_t e = nullptr;
-  ~ScopedEvent() { if (e) (void)hipEventDestroy(e); }
+  ~ThreadEvent() { if (e) (void)hipEventDestroy(e); }
+  hipError_t get(hipEvent_t* out) {
+    int d = 0;
+    hipError_t err = hipGetDevice(&d);
+    if (err != hipSuccess) return err;
+    if (e && d != dev) { (void)hipEventDestroy(e); e = nullptr; }
+    if (!e) {
+      err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+      if (err != hipSuccess) { e = nullptr; return err; }
+      dev = d;
+    }
+    *out = e;
+    return hipSuccess;
+  }
 };
+thread_local ThreadEvent g_count_event;
+
+// ---- opt-in roctx ranges: resolved at run time, so that the library has no link-time dependency
+// on a profiler; one process-wide switch (gsr_enable_markers)
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)(void);
+std::atomic<roctx_push_fn> g_roctx_push{nullptr};
+std::atomic<roctx_pop_fn> g_roctx_pop{nullptr};
+std::mutex g_roctx_mu;
+const char* const kStageNames[GSR_STAGE_COUNT] = {"preprocess_fwd", "scan_block_sums", "duplicate_with_keys", "radix_sort",
+                                                  "identify_tile_ranges", "render_fwd", "render_bwd", "preprocess_bwd"};
+const char* const kStageMarkers[GSR_STAGE_COUNT] = {"gsr:preprocess_fwd", "gsr:scan_block_sums", "gsr:duplicate_with_keys",
+                                                    "gsr:radix_sort", "gsr:identify_tile_ranges", "gsr:render_fwd",
+                                                    "gsr:render_bwd", "gsr:preprocess_bwd"};
+
+// one stage of a call: HIP-event pair on the stream when a profile handle is attached, roctx range when markers are on
 struct StageTimer {
-  Profile* pr; hipStream_t s; Profile::Span sp;
-  StageTimer(const GsrParams* p, int stage, hipStream_t st) : pr(p ? static_cast<Profile*>(p->profile) : nullptr), s(st) {
+  Profile* pr; hipStream_t s; Profile::Span sp; roctx_pop_fn pop;
+  StageTimer(const GsrParams* p, int stage, hipStream_t st)
+      : pr(p ? static_cast<Profile*>(p->profile) : nullptr), s(st), pop(nullptr) {
+    if (roctx_push_fn push = g_roctx_push.load(std::memory_order_acquire)) {
+      (void)push(kStageMarkers[stage]);
+      pop = g_roctx_pop.load(std::memory_order_acquire);
+    }
     if (!pr) return;
     sp.stage = stage; sp.a = pr->get(); sp.b = pr->get();
     if (sp.a) (void)hipEventRecord(sp.a, s);
   }
   ~StageTimer() {
-    if (!pr) return;
-    if (sp.b) (void)hipEventRecord(sp.b, s);
-    pr->push(sp);
+    if (pr) {
+      if (sp.b) (void)hipEventRecord(sp.b, s);
+      pr->push(sp);
+    }
+    if (pop) (void)pop();
   }
 };
 
@@ -156,108 +196,84 @@ size_t gsr_binning_bytes(uint32_t num_rendered, uint32_t num_visible, int32_t, i
 size_t gsr_backward_bytes(int32_t P, uint32_t num_rendered) { return BwdLayout(P, num_rendered).bytes; }
 size_t gsr_sort_scratch_bytes(uint32_t n) { return SortLayout(n).bytes; }
 
-int gsr_forward_preprocess(const GsrParams* p, void* geom_ws, int32_t* radii, void* stream, uint32_t* num_rendered,
-                           uint32_t* num_visible) {
-  if (int rc = validate(p)) return rc;
-  if (!num_rendered || !num_visible) return fail(GSR_E_BADARG, "num_rendered / num_visible is NULL");
-  *num_rendered = 0;
-  *num_visible = 0;
-  if (p->P == 0) return 0;
-  if (!geom_ws || !radii) return fail(GSR_E_BADARG, "geom_ws / radii is NULL");
-  if (((uintptr_t)geom_ws & 255u) != 0) return fail(GSR_E_ALIGN, "geom_ws must be 256-byte aligned");
-  hipStream_t s = static_cast<hipStream_t>(stream);
+}  // extern "C"
+
+static void enqueue_depth_top_pass(const GsrParams* p, void* geom_ws, hipStream_t s);
+
+// Stage 1 on the stream: preprocess, scan of the block totals (counts -> total[] and the pinned mirror), `counted`
+// recorded behind the scan, then -- two-level modes -- compaction of the visible Gaussians and their depth sort.
+// None of it needs a host-side count: the grids are sized for P and the kernels read V from the device.
+static int enqueue_stage1(const GsrParams* p, void* geom_ws, int32_t* radii, hipStream_t s, uint32_t capacity,
+                          hipEvent_t counted, bool top_pass) {
   const GeomLayout L(p->P);
   {
     StageTimer t(p, GSR_STAGE_PREPROCESS_FWD, s);
     launch_preprocess_fwd(*p, at<GeomRec>(geom_ws, L.rec), at<BinInfo>(geom_ws, L.bin),
                           at<uint32_t>(geom_ws, L.block_sums), at<uint32_t>(geom_ws, L.block_vis), radii,
-                          at<uint32_t>(geom_ws, L.total) + 2, at<uint32_t>(geom_ws, L.big_list),
+                          at<uint32_t>(geom_ws, L.total) + TOTAL_BIG, at<uint32_t>(geom_ws, L.big_list),
                           at<uint2>(geom_ws, L.block_range), s);
   }
   if (int rc = check(p, s, "preprocess_fwd")) return rc;
   uint32_t* total = at<uint32_t>(geom_ws, L.total);
   {
     StageTimer t(p, GSR_STAGE_SCAN, s);
-    launch_scan_block_sums(at<uint32_t>(geom_ws, L.block_sums), at<uint32_t>(geom_ws, L.block_offs), total,
-                           at<uint32_t>(geom_ws, L.block_vis), at<uint32_t>(geom_ws, L.block_vis_offs), total + 1,
+    launch_scan_block_sums(at<uint32_t>(geom_ws, L.block_sums), at<uint32_t>(geom_ws, L.block_offs), total + TOTAL_R,
+                           at<uint32_t>(geom_ws, L.block_vis), at<uint32_t>(geom_ws, L.block_vis_offs), total + TOTAL_V,
                            L.nblocks, s, p->counts_pinned, at<uint2>(geom_ws, L.block_range));
   }
   if (int rc = check(p, s, "scan_block_sums")) return rc;
-  uint32_t depth_min = 0, depth_max = 0;
-  ScopedEvent counted;
-  if (p->counts_pinned) {
-    GSR_HIP(hipEventCreateWithFlags(&counted.e, hipEventDisableTiming));
-    GSR_HIP(hipEventRecord(counted.e, s));
-  }
+  if (counted) GSR_HIP(hipEventRecord(counted, s));
   if (p->binning_mode != GSR_BINNING_KEYS64) {
-    // first half of the two-level binning needs no host-side count: enqueue it before the read-back so that the
-    // GPU sorts while the host round-trips (compaction + 32-bit depth sort of the visible Gaussians, device-side V)
     StageTimer t(p, GSR_STAGE_SORT, s);
     launch_compact_visible(p->P, at<BinInfo>(geom_ws, L.bin), at<uint32_t>(geom_ws, L.block_vis_offs),
                            at<uint32_t>(geom_ws, L.block_offs),
-                           p->forward_only ? nullptr : at<uint32_t>(geom_ws, L.slot_base), total + 4,
+                           p->forward_only ? nullptr : at<uint32_t>(geom_ws, L.slot_base), total, capacity,
                            (p->width + TILE - 1) / TILE, at<uint32_t>(geom_ws, L.dkey_a), at<uint2>(geom_ws, L.didx_a), s);
     launch_sort_pairs_u32_v64(at<uint32_t>(geom_ws, L.dkey_a), at<uint2>(geom_ws, L.didx_a),
                               at<uint32_t>(geom_ws, L.dkey_b), at<uint2>(geom_ws, L.didx_b), (uint32_t)p->P,
-                              DEPTH_SORT_BITS, at<char>(geom_ws, L.dsort), s, total + 1);
+                              DEPTH_SORT_BITS, at<char>(geom_ws, L.dsort), s, total + TOTAL_V);
+    if (top_pass) enqueue_depth_top_pass(p, geom_ws, s);
   }
-  if (int rc = check(p, s, "depth_sort")) return rc;
-  if (counted.e) {
-    const hipError_t e = hipEventSynchronize(counted.e);     // waits for the scan kernel only
-    if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize(counted)");
-    *num_rendered = p->counts_pinned[0];
-    *num_visible = p->counts_pinned[1];
-    depth_min = p->counts_pinned[2];
-    depth_max = p->counts_pinned[3];
-  } else {
-    uint32_t host[6] = {0, 0, 0, 0, 0, 0};
-    GSR_HIP(hipMemcpyAsync(host, total, sizeof(host), hipMemcpyDeviceToHost, s));
-    GSR_HIP(hipStreamSynchronize(s));
-    *num_rendered = host[0];
-    *num_visible = host[1];
-    depth_min = ~host[4];
-    depth_max = host[5];
-  }
-  if (p->binning_mode != GSR_BINNING_KEYS64 && *num_visible > 0 && depth_max >= depth_min &&
-      ((uint64_t)depth_max - depth_min) >> DEPTH_SORT_BITS) {
-    // more than 2^24 float32 steps of depth in one frame: sort the top digit too, then bring the indices back to where
-    // the three-pass result lives (stage 2 reads them from there)
-    StageTimer t(p, GSR_STAGE_SORT, s);
-    const bool in_b = (sort_passes(DEPTH_SORT_BITS) & 1) != 0;
-    uint32_t* k_in = at<uint32_t>(geom_ws, in_b ? L.dkey_b : L.dkey_a);
-    uint2* v_in = at<uint2>(geom_ws, in_b ? L.didx_b : L.didx_a);
-    uint32_t* k_out = at<uint32_t>(geom_ws, in_b ? L.dkey_a : L.dkey_b);
-    uint2* v_out = at<uint2>(geom_ws, in_b ? L.didx_a : L.didx_b);
-    launch_sort_extra_pass_u32(k_in, v_in, k_out, v_out, *num_visible, nullptr, DEPTH_SORT_BITS, 32 - DEPTH_SORT_BITS,
-                               at<char>(geom_ws, L.dsort), s);
-    GSR_HIP(hipMemcpyAsync(v_in, v_out, 8 * (size_t)*num_visible, hipMemcpyDeviceToDevice, s));
-    if (int rc = check(p, s, "depth_sort_top_digit")) return rc;
-  }
-  return 0;
+  return check(p, s, "depth_sort");
 }
 
-int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t bin_ws_bytes, void* img_ws,
-                       uint32_t R, uint32_t V, float* out_color, void* stream) {
-  if (int rc = validate(p)) return rc;
-  if (!img_ws || !out_color) return fail(GSR_E_BADARG, "img_ws / out_color is NULL");
-  hipStream_t s = static_cast<hipStream_t>(stream);
+// The depth sort's fourth pass (bits 24..31 of the relative depth key).  Its element count is total[TOTAL_TOP_PASS_N]:
+// V for a frame that spans more than 2^24 float32 steps of depth, 0 otherwise (the three kernels then exit at once).
+// The consumers (count_tiles / emit_instances) read the same word to pick the buffer the sorted payload ended in.
+static void enqueue_depth_top_pass(const GsrParams* p, void* geom_ws, hipStream_t s) {
+  const GeomLayout L(p->P);
+  const bool in_b = (sort_passes(DEPTH_SORT_BITS) & 1) != 0;
+  launch_sort_extra_pass_u32(at<uint32_t>(geom_ws, in_b ? L.dkey_b : L.dkey_a), at<uint2>(geom_ws, in_b ? L.didx_b : L.didx_a),
+                             at<uint32_t>(geom_ws, in_b ? L.dkey_a : L.dkey_b), at<uint2>(geom_ws, in_b ? L.didx_a : L.didx_b),
+                             (uint32_t)p->P, at<uint32_t>(geom_ws, L.total) + TOTAL_TOP_PASS_N, DEPTH_SORT_BITS,
+                             32 - DEPTH_SORT_BITS, at<char>(geom_ws, L.dsort), s);
+}
+
+// Stage 2 on the stream: instance emission, tile sort, tile ranges, compositing.  (r_cap, v_cap) are what the binning
+// workspace is laid out for: the real counts in the two-call forward (device_counts = false), the caller's capacity
+// and P in gsr_forward (device_counts = true: every kernel takes the real counts from total[]).
+static int enqueue_stage2(const GsrParams* p, void* geom_ws, void* bin_ws, size_t bin_ws_bytes, void* img_ws,
+                          uint32_t r_cap, uint32_t v_cap, bool device_counts, float* out_color, hipStream_t s) {
   const ImageLayout I(p->width, p->height);
   uint2* ranges = at<uint2>(img_ws, I.ranges);
   GSR_HIP(hipMemsetAsync(ranges, 0, 8 * (size_t)I.tiles, s));
   const uint32_t* point_list = nullptr;
   const GeomRec* rec = nullptr;
-  if (p->P > 0 && R > 0) {
+  if (p->P > 0 && r_cap > 0) {
     if (!geom_ws || !bin_ws) return fail(GSR_E_BADARG, "geom_ws / bin_ws is NULL");
-    if (V == 0 || V > R || V > (uint32_t)p->P) return fail(GSR_E_BADARG, "num_visible inconsistent with num_rendered / P");
+    if (v_cap == 0 || v_cap > (uint32_t)p->P || (!device_counts && v_cap > r_cap))
+      return fail(GSR_E_BADARG, "num_visible inconsistent with num_rendered / P");
     const int mode = p->binning_mode;
-    const BinLayout B(R, V, mode);
+    const BinLayout B(r_cap, v_cap, mode);
     if (bin_ws_bytes < B.bytes) return fail(GSR_E_CAPACITY, "binning workspace too small for num_rendered / num_visible");
     if (((uintptr_t)bin_ws & 255u) != 0) return fail(GSR_E_ALIGN, "bin_ws must be 256-byte aligned");
     const GeomLayout L(p->P);
     rec = at<GeomRec>(geom_ws, L.rec);
     const BinInfo* bin = at<BinInfo>(geom_ws, L.bin);
+    const uint32_t* total = at<uint32_t>(geom_ws, L.total);
     const int tb = tile_bits(I.tiles);
     if (mode == GSR_BINNING_KEYS64) {
+      if (device_counts) return fail(GSR_E_BADARG, "gsr_forward supports the two-level binning modes only");
       uint64_t* ka = at<uint64_t>(bin_ws, B.keys_a);
       uint64_t* kb = at<uint64_t>(bin_ws, B.keys_b);
       uint32_t* va = at<uint32_t>(bin_ws, B.vals_a);
@@ -271,12 +287,12 @@ int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t b
       bool in_b;
       {
         StageTimer t(p, GSR_STAGE_SORT, s);
-        in_b = launch_sort_pairs(ka, va, kb, vb, R, 32 + tb, at<char>(bin_ws, B.sort), s);
+        in_b = launch_sort_pairs(ka, va, kb, vb, r_cap, 32 + tb, at<char>(bin_ws, B.sort), s);
       }
       if (int rc = check(p, s, "sort_pairs")) return rc;
       {
         StageTimer t(p, GSR_STAGE_RANGES, s);
-        launch_identify_tile_ranges(R, in_b ? kb : ka, ranges, s);
+        launch_identify_tile_ranges(r_cap, in_b ? kb : ka, ranges, s);
       }
       point_list = in_b ? vb : va;
     } else {
@@ -286,24 +302,28 @@ int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t b
       uint32_t* igb = at<uint32_t>(bin_ws, B.ig_b);
       uint32_t* bsum2 = at<uint32_t>(bin_ws, B.bsum2);
       uint32_t* boffs2 = at<uint32_t>(bin_ws, B.boffs2);
-      // depth-sorted Gaussian indices: produced by stage 1 (gsr_forward_preprocess) in the geometry workspace
-      const uint2* dval_sorted = at<uint2>(geom_ws, (sort_passes(DEPTH_SORT_BITS) & 1) ? L.didx_b : L.didx_a);
+      // depth-sorted payload: produced by stage 1 in the geometry workspace, in d3 or (after the top-digit pass) in d4
+      const bool in_b3 = (sort_passes(DEPTH_SORT_BITS) & 1) != 0;
+      const uint2* d3 = at<uint2>(geom_ws, in_b3 ? L.didx_b : L.didx_a);
+      const uint2* d4 = at<uint2>(geom_ws, in_b3 ? L.didx_a : L.didx_b);
+      const uint32_t cap = device_counts ? r_cap : 0xffffffffu;
       {
         StageTimer t(p, GSR_STAGE_DUPLICATE, s);   // instances emitted in depth order
-        launch_count_tiles(V, dval_sorted, bin, bsum2, s);
+        launch_count_tiles(v_cap, total, d3, d4, bin, bsum2, s);
         launch_scan_block_sums(bsum2, boffs2, boffs2 + B.nblocks2 + 1, nullptr, nullptr, nullptr, (int)B.nblocks2, s);
-        launch_emit_instances(V, I.grid_x, dval_sorted, bin, boffs2, ita, iga, s);
+        launch_emit_instances(v_cap, total, I.grid_x, d3, d4, bin, boffs2, ita, iga, cap, s);
       }
       if (int rc = check(p, s, "emit_instances")) return rc;
+      const uint32_t* r_dev = device_counts ? total + TOTAL_R_CLAMPED : nullptr;
       bool in_b;
       {
         StageTimer t(p, GSR_STAGE_SORT, s);     // stable partition by tile id
-        in_b = launch_sort_pairs_u32(ita, iga, itb, igb, R, tb, at<char>(bin_ws, B.sort), s);
+        in_b = launch_sort_pairs_u32(ita, iga, itb, igb, r_cap, tb, at<char>(bin_ws, B.sort), s, r_dev);
       }
       if (int rc = check(p, s, "tile_sort")) return rc;
       {
         StageTimer t(p, GSR_STAGE_RANGES, s);
-        launch_identify_tile_ranges_u32(R, in_b ? itb : ita, ranges, s);
+        launch_identify_tile_ranges_u32(r_cap, in_b ? itb : ita, ranges, s, r_dev);
       }
       point_list = in_b ? igb : iga;
     }
@@ -315,9 +335,128 @@ int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t b
     const bool track = !p->forward_only;
     launch_render_fwd(p->width, p->height, ranges, point_list, rec, p->bg, out_color,
                       track ? at<float>(img_ws, I.final_T) : nullptr, track ? at<uint32_t>(img_ws, I.n_contrib) : nullptr,
-                      track ? at<uint32_t>(img_ws, I.tile_max) : nullptr, at<uint32_t>(img_ws, I.tile_order), s);
+                      track ? at<uint32_t>(img_ws, I.tile_max) : nullptr, at<uint32_t>(img_ws, I.tile_order), s, nullptr,
+                      (p->debug_flags & GSR_DEBUG_NO_MINIBLOCK_CULL) ? 0 : 1);
   }
   return check(p, s, "render_fwd");
+}
+
+extern "C" {
+
+int gsr_forward_preprocess(const GsrParams* p, void* geom_ws, int32_t* radii, void* stream, uint32_t* num_rendered,
+                           uint32_t* num_visible) {
+  if (int rc = validate(p)) return rc;
+  if (!num_rendered || !num_visible) return fail(GSR_E_BADARG, "num_rendered / num_visible is NULL");
+  *num_rendered = 0;
+  *num_visible = 0;
+  if (p->P == 0) return 0;
+  if (!geom_ws || !radii) return fail(GSR_E_BADARG, "geom_ws / radii is NULL");
+  if (((uintptr_t)geom_ws & 255u) != 0) return fail(GSR_E_ALIGN, "geom_ws must be 256-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const GeomLayout L(p->P);
+  hipEvent_t counted = nullptr;
+  if (p->counts_pinned) GSR_HIP(g_count_event.get(&counted));
+  // the first half of the two-level binning is enqueued before the read-back, so that the GPU sorts while the host
+  // round-trips; the top-digit pass follows only for the frames that need it (the host knows once the counts are in)
+  if (int rc = enqueue_stage1(p, geom_ws, radii, s, 0xffffffffu, counted, false)) return rc;
+  uint32_t depth_min = 0, depth_max = 0;
+  if (counted) {
+    const hipError_t e = hipEventSynchronize(counted);     // waits for the scan kernel only
+    if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize(counted)");
+    *num_rendered = p->counts_pinned[0];
+    *num_visible = p->counts_pinned[1];
+    depth_min = p->counts_pinned[2];
+    depth_max = p->counts_pinned[3];
+  } else {
+    uint32_t host[6] = {0, 0, 0, 0, 0, 0};
+    GSR_HIP(hipMemcpyAsync(host, at<uint32_t>(geom_ws, L.total), sizeof(host), hipMemcpyDeviceToHost, s));
+    GSR_HIP(hipStreamSynchronize(s));
+    *num_rendered = host[TOTAL_R];
+    *num_visible = host[TOTAL_V];
+    depth_min = ~host[TOTAL_DEPTH_INV_MIN];
+    depth_max = host[TOTAL_DEPTH_MAX];
+  }
+  if (p->binning_mode != GSR_BINNING_KEYS64 && *num_visible > 0 && depth_max >= depth_min &&
+      ((uint64_t)depth_max - depth_min) >> DEPTH_SORT_BITS) {
+    StageTimer t(p, GSR_STAGE_SORT, s);
+    enqueue_depth_top_pass(p, geom_ws, s);
+    if (int rc = check(p, s, "depth_sort_top_digit")) return rc;
+  }
+  return 0;
+}
+
+int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t bin_ws_bytes, void* img_ws,
+                       uint32_t R, uint32_t V, float* out_color, void* stream) {
+  if (int rc = validate(p)) return rc;
+  if (!img_ws || !out_color) return fail(GSR_E_BADARG, "img_ws / out_color is NULL");
+  return enqueue_stage2(p, geom_ws, bin_ws, bin_ws_bytes, img_ws, R, V, false, out_color, static_cast<hipStream_t>(stream));
+}
+
+int gsr_forward(const GsrParams* p, void* geom_ws, void* bin_ws, size_t bin_ws_bytes, uint32_t capacity, void* img_ws,
+                int32_t* radii, float* out_color, void* counts_event, void* stream) {
+  if (int rc = validate(p)) return rc;
+  if (!img_ws || !out_color) return fail(GSR_E_BADARG, "img_ws / out_color is NULL");
+  if (p->P > 0 && p->binning_mode == GSR_BINNING_KEYS64)
+    return fail(GSR_E_BADARG, "gsr_forward supports the two-level binning modes only");
+  if (p->P > 0 && !p->counts_pinned)
+    return fail(GSR_E_BADARG, "gsr_forward needs counts_pinned (the caller detects an overflow of `capacity` there)");
+  if (p->P > 0 && capacity == 0) return fail(GSR_E_BADARG, "capacity is 0");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (p->P > 0) {
+    if (!geom_ws || !radii) return fail(GSR_E_BADARG, "geom_ws / radii is NULL");
+    if (((uintptr_t)geom_ws & 255u) != 0) return fail(GSR_E_ALIGN, "geom_ws must be 256-byte aligned");
+    if (int rc = enqueue_stage1(p, geom_ws, radii, s, capacity, static_cast<hipEvent_t>(counts_event), true)) return rc;
+  } else if (counts_event) {
+    GSR_HIP(hipEventRecord(static_cast<hipEvent_t>(counts_event), s));
+  }
+  return enqueue_stage2(p, geom_ws, bin_ws, bin_ws_bytes, img_ws, p->P > 0 ? capacity : 0u, (uint32_t)p->P, true, out_color, s);
+}
+
+int gsr_event_create(void** event) {
+  if (!event) return fail(GSR_E_BADARG, "event is NULL");
+  hipEvent_t e = nullptr;
+  GSR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  *event = e;
+  return 0;
+}
+int gsr_event_destroy(void* event) {
+  if (event) GSR_HIP(hipEventDestroy(static_cast<hipEvent_t>(event)));
+  return 0;
+}
+int gsr_event_wait(void* event) {
+  if (!event) return fail(GSR_E_BADARG, "event is NULL");
+  GSR_HIP(hipEventSynchronize(static_cast<hipEvent_t>(event)));
+  return 0;
+}
+int gsr_event_query(void* event, int32_t* done) {
+  if (!event || !done) return fail(GSR_E_BADARG, "NULL argument");
+  const hipError_t e = hipEventQuery(static_cast<hipEvent_t>(event));
+  if (e != hipSuccess && e != hipErrorNotReady) return hip_fail(e, "hipEventQuery");
+  *done = e == hipSuccess ? 1 : 0;
+  return 0;
+}
+
+int gsr_enable_markers(int32_t on) {
+  std::lock_guard<std::mutex> lock(g_roctx_mu);
+  if (!on) {
+    g_roctx_push.store(nullptr, std::memory_order_release);
+    return 0;
+  }
+  if (g_roctx_push.load(std::memory_order_acquire)) return 0;
+  static const char* const libs[] = {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so",
+                                     "libroctx64.so.4"};
+  for (const char* name : libs) {
+    void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) continue;
+    roctx_push_fn push = reinterpret_cast<roctx_push_fn>(dlsym(h, "roctxRangePushA"));
+    roctx_pop_fn pop = reinterpret_cast<roctx_pop_fn>(dlsym(h, "roctxRangePop"));
+    if (push && pop) {
+      g_roctx_pop.store(pop, std::memory_order_release);
+      g_roctx_push.store(push, std::memory_order_release);
+      return 0;
+    }
+  }
+  return fail(GSR_E_BADARG, "no roctx library found (librocprofiler-sdk-roctx.so / libroctx64.so)");
 }
 
 int gsr_backward(const GsrParams* p, const int32_t* radii, const void* geom_ws, const void* bin_ws, const void* img_ws,
@@ -336,6 +475,11 @@ int gsr_backward(const GsrParams* p, const int32_t* radii, const void* geom_ws, 
   if (p->shs && !p->shs_rest && p->M == 16 && ((uintptr_t)grads->dL_dshs & 15u) != 0)
     return fail(GSR_E_ALIGN, "dL_dshs must be 16-byte aligned");
   if (p->colors_precomp && !grads->dL_dcolors) return fail(GSR_E_BADARG, "dL_dcolors required with colors_precomp");
+  {
+    const int n_stats = (grads->stats_xyz_gradient_accum != nullptr) + (grads->stats_denom != nullptr) +
+                        (grads->stats_max_radii2D != nullptr);
+    if (n_stats != 0 && n_stats != 3) return fail(GSR_E_BADARG, "the three stats_* pointers must be given together");
+  }
   const BwdLayout Wl(p->P, R);
   if (bwd_ws_bytes < Wl.bytes) return fail(GSR_E_CAPACITY, "backward workspace too small");
   if (((uintptr_t)bwd_ws & 255u) != 0) return fail(GSR_E_ALIGN, "bwd_ws must be 256-byte aligned");
@@ -405,9 +549,7 @@ int gsr_profile_collect(void* handle, double* ms_sum, uint32_t* counts) {
   return 0;
 }
 const char* gsr_stage_name(int32_t stage) {
-  static const char* names[GSR_STAGE_COUNT] = {"preprocess_fwd", "scan_block_sums", "duplicate_with_keys", "radix_sort",
-                                               "identify_tile_ranges", "render_fwd", "render_bwd", "preprocess_bwd"};
-  return (stage >= 0 && stage < GSR_STAGE_COUNT) ? names[stage] : "?";
+  return (stage >= 0 && stage < GSR_STAGE_COUNT) ? kStageNames[stage] : "?";
 }
 
 // Re-runs the forward compositing with work counters (debug / tuning only):
@@ -425,7 +567,8 @@ int gsr_debug_render_stats(const GsrParams* p, const void* geom_ws, const void* 
                     sorted_views(bin_ws, R, V, p->width, p->height, p->binning_mode).point_list,
                     at<GeomRec>(geom_ws, L.rec), p->bg, out_color, at<float>(img_ws, I.final_T),
                     at<uint32_t>(img_ws, I.n_contrib), at<uint32_t>(img_ws, I.tile_max),
-                    at<uint32_t>(img_ws, I.tile_order), s, stats);
+                    at<uint32_t>(img_ws, I.tile_order), s, stats,
+                    (p->debug_flags & GSR_DEBUG_NO_MINIBLOCK_CULL) ? 0 : 1);
   return check(p, s, "render_stats");
 }
 
@@ -472,7 +615,7 @@ int gsr_debug_read_binning(const void* geom_ws, int32_t P, const void* bin_ws, u
       GSR_HIP(hipMemcpyAsync(keys_sorted, v.keys_sorted, 8 * (size_t)R, hipMemcpyDeviceToDevice, s));
     } else {
       const GeomLayout L(P);
-      launch_reconstruct_keys(R, v.tile_sorted, v.point_list, at<BinInfo>(geom_ws, L.bin), keys_sorted, s);
+      launch_reconstruct_keys(R, (uint32_t)P, v.tile_sorted, v.point_list, at<BinInfo>(geom_ws, L.bin), keys_sorted, s);
     }
   }
   if (point_list) GSR_HIP(hipMemcpyAsync(point_list, v.point_list, 4 * (size_t)R, hipMemcpyDeviceToDevice, s));

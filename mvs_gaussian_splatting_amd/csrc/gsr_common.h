@@ -126,8 +126,7 @@ struct GeomLayout {
     block_vis = o;  o = align_up(o + 4 * (size_t)(nblocks + 1), 256);        // visible Gaussians per block
     block_vis_offs = o; o = align_up(o + 4 * (size_t)(nblocks + 1), 256);
     block_range = o; o = align_up(o + 8 * (size_t)(nblocks + 1), 256);       // per block: max(~depth bits), max(depth bits)
-    total = o;      o = align_up(o + 64, 256);                               // [0] = R (instances), [1] = V (visible),
-                                                                             // [2] = entries of big_list
+    total = o;      o = align_up(o + 64, 256);                               // the TOTAL_* words below
     dkey_a = o;     o = align_up(o + 4 * (size_t)P, 256);
     dkey_b = o;     o = align_up(o + 4 * (size_t)P, 256);
     didx_a = o;     o = align_up(o + 8 * (size_t)P, 256);    // payload: (index, packed rect)
@@ -137,6 +136,18 @@ struct GeomLayout {
     bytes = o;
   }
 };
+
+// words of GeomLayout::total
+enum {
+  TOTAL_R = 0,              // instances (sum of tiles_touched)
+  TOTAL_V = 1,              // visible Gaussians
+  TOTAL_BIG = 2,            // entries of big_list
+  TOTAL_DEPTH_INV_MIN = 4,  // ~(smallest depth key of the frame)
+  TOTAL_DEPTH_MAX = 5,      // largest depth key
+  TOTAL_TOP_PASS_N = 6,     // V when the depth sort needs its top-digit pass, else 0
+  TOTAL_R_CLAMPED = 7       // min(R, capacity of the binning workspace)
+};
+constexpr int DEPTH_SORT_BITS = 24;   // see gsr_launch.h
 
 struct ImageLayout {
   size_t final_T, n_contrib, ranges, tile_max, tile_order, bytes;
@@ -245,6 +256,10 @@ __device__ inline float qmin_rect(float cxx, float cxy, float cyy, float icxx, f
   // minimum over [y0,y1] is q(0, ye) >= the horizontal edge's minimum -- taking the min with it is harmless
   return (xe == 0.0f && ye == 0.0f) ? 0.0f : fminf(xe != 0.0f ? qv : qh, ye != 0.0f ? qh : qv);
 }
+
+// ||dL_dmeans2D.xy|| of the densification statistics: one fixed operation order (an explicit fma), so that the fused
+// epilogue of preprocess_bwd (built without contraction) and the stand-alone kernel give the same bits
+__device__ inline float densify_grad_norm(float gx, float gy) { return sqrtf(__builtin_fmaf(gx, gx, gy * gy)); }
 
 // ---- wave helpers --------------------------------------------------------------------------
 __device__ inline int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0)); }

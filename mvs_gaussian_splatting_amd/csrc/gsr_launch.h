@@ -29,13 +29,17 @@ bool launch_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uin
 // n_dev != NULL: the element count is read from device memory and n is the capacity the grid is sized for
 bool launch_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n,
                            int end_bit, void* scratch, hipStream_t s, const uint32_t* n_dev = nullptr);
-void launch_identify_tile_ranges_u32(uint32_t R, const uint32_t* tiles, uint2* ranges, hipStream_t s);
+// r_dev != NULL: the instance count is read from device memory and R is the capacity the grid is sized for
+void launch_identify_tile_ranges_u32(uint32_t R, const uint32_t* tiles, uint2* ranges, hipStream_t s,
+                                     const uint32_t* r_dev = nullptr);
 inline int sort_passes(int end_bit) { return (end_bit + RADIX_BITS - 1) / RADIX_BITS; }
 void launch_identify_tile_ranges(uint32_t R, const uint64_t* keys, uint2* ranges, hipStream_t s);
 void launch_build_tile_order(int tiles, const uint2* ranges, uint32_t* order, hipStream_t s);
+// also derives the device-side counts of the later stages (GeomLayout::total[TOTAL_TOP_PASS_N / TOTAL_R_CLAMPED]);
+// capacity: instances the binning workspace holds (0xffffffff when the host sizes it from the real count)
 void launch_compact_visible(int P, const BinInfo* bin, const uint32_t* block_vis_offs, const uint32_t* block_offs,
-                            uint32_t* slot_base, const uint32_t* depth_inv_min, int grid_x, uint32_t* dkey, uint2* dval,
-                            hipStream_t s);
+                            uint32_t* slot_base, uint32_t* total, uint32_t capacity, int grid_x, uint32_t* dkey,
+                            uint2* dval, hipStream_t s);
 // (32-bit key, 64-bit value) pairs: the depth sort, whose payload is (index, packed rect)
 bool launch_sort_pairs_u32_v64(uint32_t* keys_a, uint2* vals_a, uint32_t* keys_b, uint2* vals_b, uint32_t n,
                                int end_bit, void* scratch, hipStream_t s, const uint32_t* n_dev = nullptr);
@@ -43,19 +47,22 @@ void launch_sort_extra_pass_u32(const uint32_t* kin, const uint2* vin, uint32_t*
                                 const uint32_t* n_dev, int shift, int nbits, void* scratch, hipStream_t s);
 // The two-level binning sorts the visible Gaussians on (depth bits - smallest depth bits of the frame).  Three 8-bit
 // passes (24 bits: up to two binades of depth, e.g. 3 .. 12) are enqueued before the host knows the counts; a frame
-// that spans more gets the fourth 8-bit pass on bits 24..31 once the range has been read back with the counts.
+// that spans more gets the fourth 8-bit pass on bits 24..31: its kernels take their element count from
+// total[TOTAL_TOP_PASS_N] (V or 0, set on the device), and the consumers pick the buffer the result ended in.
 // (Three 9-bit passes were measured too: as slow as four 8-bit ones -- wider digits rank and scatter more slowly.)
-constexpr int DEPTH_SORT_BITS = 24;
-void launch_count_tiles(uint32_t V, const uint2* dval, const BinInfo* bin, uint32_t* block_sums2, hipStream_t s);
-void launch_emit_instances(uint32_t V, int grid_x, const uint2* dval, const BinInfo* bin, const uint32_t* block_offs2,
-                           uint32_t* inst_tile, uint32_t* inst_g, hipStream_t s);
-void launch_reconstruct_keys(uint32_t R, const uint32_t* tile_sorted, const uint32_t* point_list, const BinInfo* bin,
-                             uint64_t* keys, hipStream_t s);
+// d3 / d4: the depth-sorted payload after the three regular passes / after the top-digit pass (chosen on the device)
+void launch_count_tiles(uint32_t v_cap, const uint32_t* total, const uint2* d3, const uint2* d4, const BinInfo* bin,
+                        uint32_t* block_sums2, hipStream_t s);
+void launch_emit_instances(uint32_t v_cap, const uint32_t* total, int grid_x, const uint2* d3, const uint2* d4,
+                           const BinInfo* bin, const uint32_t* block_offs2, uint32_t* inst_tile, uint32_t* inst_g,
+                           uint32_t capacity, hipStream_t s);
+void launch_reconstruct_keys(uint32_t R, uint32_t P, const uint32_t* tile_sorted, const uint32_t* point_list,
+                             const BinInfo* bin, uint64_t* keys, hipStream_t s);
 
 // render.hip
 void launch_render_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
                        const float* bg, float* out_color, float* final_T, uint32_t* n_contrib, uint32_t* tile_max,
-                       const uint32_t* tile_order, hipStream_t s, unsigned long long* stats = nullptr);
+                       const uint32_t* tile_order, hipStream_t s, unsigned long long* stats = nullptr, int cull = 1);
 void launch_render_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
                        const uint32_t* slot_base,
                        const float* bg, const float* final_T, const uint32_t* n_contrib, const uint32_t* tile_max,

@@ -894,6 +894,13 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(GsrParams p, 
   g.dL_dmeans2D[3 * (size_t)idx + 1] = dm2y;
   g.dL_dmeans2D[3 * (size_t)idx + 2] = 0.0f;
   g.dL_dopacities[idx] = dop;
+  if (g.stats_xyz_gradient_accum && vis) {
+    // densification statistics of the reference's training loop (scene/gaussian_model.py:775-777, train.py:130),
+    // fused here because dL_dmeans2D and the radius are in registers: saves the stand-alone kernel's re-read
+    g.stats_xyz_gradient_accum[idx] += densify_grad_norm(dm2x, dm2y);
+    g.stats_denom[idx] += 1.0f;
+    g.stats_max_radii2D[idx] = fmaxf(g.stats_max_radii2D[idx], (float)radii[idx]);
+  }
   if (g.dL_dcolors) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) g.dL_dcolors[3 * (size_t)idx + i] = dcol[i];

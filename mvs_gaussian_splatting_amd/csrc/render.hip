@@ -13,13 +13,13 @@
 // different (instance, mini-block) pairs.  A 7x7-pixel footprint costs ~7 groups of 16 lanes instead of ~3.5 sub-blocks
 // of 64.  Skipped pairs would have been rejected pixel by pixel by the alpha test, so results are unchanged.
 //
-// BACKWARD: one wave per tile, four pixels per lane (one per 8x8 sub-block), because the nine per-instance gradient sums
-// must be reduced across the pixels of the tile: per-instance gradients are reduced across the wave in registers (DPP /
-// permlane swaps) and written as one row per (Gaussian, tile) instance -- no atomics; preprocess_bwd sums the rows.
+// BACKWARD: one wave per tile; every 16-lane group (a DPP row) owns one 8x8 sub-block (a 2x2 pixel quad per lane) and
+// walks its own list of the round's instances that reach it.  The nine per-instance gradient sums are folded over the
+// row with DPP, added to a per-wave LDS slab and written as one row per (Gaussian, tile) instance -- no atomics;
+// preprocess_bwd sums the rows.
 #include "gsr_common.h"
 #include "gsr_launch.h"
 #include <type_traits>
-#include <stdlib.h>
 
 namespace gsr {
 
@@ -343,14 +343,10 @@ __global__ __launch_bounds__(256, TRACK ? 7 : 8) void render_fwd_kernel(int W, i
     __syncthreads();
     // ---- (d) every 16-lane group walks its own list --------------------------------------------------------------
     if (STATS) { st_pairs += (q == 0) ? n_lane : 0u; st_evals += (lane == 0) ? nmax : 0u; }
-#ifndef GSR_EXPERIMENT_NO_WALK     // tuning experiment: staging / culling / compaction only
     uint32_t last_e = 0xffffffffu;        // list entry (16 * slot) of the round's last contributor
     if (clamp) walk_lists<TRACK, true>(mylist, nmax, (const char*)sA, (const char*)sB, (const char*)sC, pxf, pyf, T, Cr, Cg, Cb, last_e);
     else       walk_lists<TRACK, false>(mylist, nmax, (const char*)sA, (const char*)sB, (const char*)sC, pxf, pyf, T, Cr, Cg, Cb, last_e);
     if (TRACK && last_e != 0xffffffffu) last = base + 1u + (last_e >> 4);
-#else
-    if (clamp && nmax == 0xffffffffu) T = 0.0f;
-#endif
     // ---- (e) stop when every pixel of the tile is parked; also fences the LDS reuse ------------------------------
     if (__syncthreads_and(!(T > 0.0f))) break;
   }
@@ -398,214 +394,11 @@ __device__ inline float dpp_add(float v) {
   const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
   return v + __int_as_float(moved);
 }
-// every lane ends with the sum over its 16-lane row
-__device__ inline float row_sum16(float v) {
-  v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
-  v = dpp_add<0x141>(v);   // row_half_mirror
-  v = dpp_add<0x140>(v);   // row_mirror
-  return v;
-}
-// one value summed over the wave with DPP alone (six half-rate adds; the swap-based folds below pay off only when they
-// carry two values at once): every lane of row 3 (lanes 48..63) ends with the total
-__device__ inline float wave_sum1_row3(float v) {
-  v = row_sum16(v);
-  // v_add_f32_dpp leaves the rows outside row_mask untouched: one instruction per step (the builtin form, with its
-  // separate `old` operand, costs three).  The s_nop covers the VALU-write -> DPP-read hazard the assembler cannot see.
-  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-               "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
-               : "+v"(v));
-  return v;
-}
-// lanes 0..31 end with x[i] + x[i+32], lanes 32..63 with y[i-32] + y[i]
-__device__ inline float fold32(float x, float y) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-// rows (0,1,2,3) end with (x.r0 + x.r1, y.r0 + y.r1, x.r2 + x.r3, y.r2 + y.r3)
-__device__ inline float fold16(float x, float y) {
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-// Wave-wide sums of four values at once: row 0 of the result holds sum(q0), row 1 sum(q2),
-// row 2 sum(q1), row 3 sum(q3) (every lane of the row).  10 VALU ops instead of 24.
-__device__ inline float wave_sum4(float q0, float q1, float q2, float q3) {
-  return row_sum16(fold16(fold32(q0, q1), fold32(q2, q3)));
-}
-
-__device__ __forceinline__ void render_bwd_tile(const int tile, float4* sA, float4* sB, float* sC, int W, int H,
-                                                int grid_x, const uint2* __restrict__ ranges,
-                                                const uint32_t* __restrict__ point_list,
-                                                const GeomRec* __restrict__ rec,
-                                                const uint32_t* __restrict__ slot_base, const float* __restrict__ bg,
-                                                const float* __restrict__ final_T,
-                                                const uint32_t* __restrict__ n_contrib,
-                                                const uint32_t* __restrict__ tile_max,
-                                                const float* __restrict__ dL_dpix, GradRow* __restrict__ rows,
-                                                uint8_t* __restrict__ row_flags) {
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int tile_x = tile % grid_x, tile_y = tile / grid_x;
-  const int px0 = tile_x * TILE + (lane & 7), py0 = tile_y * TILE + (lane >> 3);
-  const float tx0 = (float)(tile_x * TILE), ty0 = (float)(tile_y * TILE);
-  // pixel coordinates of the lane's four pixels (sub-block k: x index k & 1, y index k >> 1): dx = mean - pixel is formed
-  // by ONE subtraction from the exact integer coordinate, as in the forward and in the reference
-  float pxf0 = (float)px0, pxf1 = (float)(px0 + 8), pyf0 = (float)py0, pyf1 = (float)(py0 + 8);
-  asm volatile("" : "+v"(pxf0), "+v"(pxf1), "+v"(pyf0), "+v"(pyf1));      // keep them in registers
-  const size_t HW = (size_t)W * H;
-  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-
-  // per pixel: T (running transmittance in front of the current instance), Bk = sum over the
-  // instances behind of (c.dL_dpix)*alpha*T  +  T_final*(bg.dL_dpix)
-  float T[4], Bk[4], dpr[4], dpg[4], dpb[4];
-  uint32_t last[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int px = px0 + 8 * (k & 1), py = py0 + 8 * (k >> 1);
-    const bool in = px < W && py < H;
-    const size_t pix = (size_t)py * W + px;
-    T[k] = in ? final_T[pix] : 0.0f;
-    last[k] = in ? n_contrib[pix] : 0u;
-    dpr[k] = in ? dL_dpix[pix] : 0.0f;
-    dpg[k] = in ? dL_dpix[HW + pix] : 0.0f;
-    dpb[k] = in ? dL_dpix[2 * HW + pix] : 0.0f;
-    Bk[k] = T[k] * (bg0 * dpr[k] + bg1 * dpg[k] + bg2 * dpb[k]);
-  }
-
-  const uint2 range = ranges[tile];
-  const uint32_t start = range.x;
-  uint32_t hi = min(range.y - range.x, tile_max[tile]);   // instances past the last contributor get no gradient
-  // the same per 8x8 sub-block: the largest contributor index of its 64 pixels (a sub-block behind an opaque surface
-  // stops long before the rest of the tile)
-  uint32_t sub_last[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    uint32_t mx = last[k];
-#pragma unroll
-    for (int d = WAVE / 2; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, WAVE));
-    sub_last[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)mx);
-  }
-
-  Staged st;
-  st.q0 = st.q1 = st.q2 = make_float4(0.f, 0.f, 0.f, 0.f);
-  st.kk = st.isyy = 0.0f;
-  st.rect_min = st.rect_wh = st.slot_base = 0;
-  // unconditional, index-clamped staging loads (see the forward kernel): ids two rounds ahead,
-  // records one round ahead, walking the list back to front
-  auto load_id = [&](uint32_t lo, uint32_t top) { return point_list[start + min(lo + lane, top - 1)]; };
-  auto load_rec = [&](uint32_t id) {
-    load_staged<true>(rec, id, st);          // q2.w = tile_mask
-    st.slot_base = slot_base[id];
-    const uint2 rr = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(rec + id) + 48);
-    st.rect_min = rr.x;
-    st.rect_wh = rr.y;
-  };
-  uint32_t lo = hi > BATCH ? hi - BATCH : 0u;
-  uint32_t id_next = 0;
-  if (hi > 0) {
-    load_rec(load_id(lo, hi));
-    const uint32_t lo2 = lo > BATCH ? lo - BATCH : 0u;
-    id_next = load_id(lo2, max(lo, 1u));
-  }
-
-  while (hi > 0) {
-    const bool have = lo + lane < hi;
-    uint32_t m = have ? subblock_mask(st.q0.x, st.q0.y, st.q2.y, st.q2.z, st.q0.z, st.q0.w, st.q1.x, st.q1.y, tx0, ty0) : 0u;
-    if (st.q1.y > ALPHA_MAX) m |= m ? 16u : 0u;      // bit 4: the 0.99 clamp can be reached (opacity <= 0.99: exp2(p2 <= 0) <= 1)
-    // gradient-row slot of this instance: the Gaussian's first slot + the rank of this tile among its instances
-    const uint32_t rw = st.rect_wh & 0xffffu;
-    const uint32_t bit = ((uint32_t)tile_y - rect_min_y(st.rect_min)) * rw + ((uint32_t)tile_x - rect_min_x(st.rect_min));
-    const uint32_t slot = st.slot_base + bin_rank(st.rect_wh, __float_as_uint(st.q2.w), have ? bit : 0u);
-    LdsRec lr;
-    make_lds(st, lr);
-    __builtin_amdgcn_wave_barrier();
-    sA[lane] = lr.A;
-    sB[lane] = lr.B;
-    sC[lane] = st.q2.x;
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t cur_lo = lo;
-    // sub-blocks that still have a contributor in this round (1-based indices cur_lo + 1 .. hi); bit 4 = clamp flag
-    const uint32_t active = 16u | (sub_last[0] > cur_lo ? 1u : 0u) | (sub_last[1] > cur_lo ? 2u : 0u) |
-                            (sub_last[2] > cur_lo ? 4u : 0u) | (sub_last[3] > cur_lo ? 8u : 0u);
-    hi = lo;
-    lo = hi > BATCH ? hi - BATCH : 0u;
-    {   // prefetch: record of the next (earlier) round, ids of the one after it
-      load_rec(id_next);
-      const uint32_t lo2 = lo > BATCH ? lo - BATCH : 0u;
-      id_next = load_id(lo2, max(lo, 1u));
-    }
-
-    unsigned long long nz = __ballot(m != 0u);
-    while (nz) {
-      const int j = 63 - __clzll((long long)nz);   // back to front
-      nz &= ~(1ull << j);
-      const uint32_t mj = (uint32_t)__builtin_amdgcn_readlane((int)m, j) & active;
-      if ((mj & 15u) == 0u) continue;
-      const float4 a = sA[j];
-      const float4 b = sB[j];
-      const float cb = sC[j];
-      const uint32_t pos1 = cur_lo + (uint32_t)j + 1u;
-      // per-lane partial sums over the sub-blocks; un-scaled forms (constants applied after the reduction):
-      //   g_mx = sum h dx, g_my = sum h dy (first moments), g_xx = sum h dx^2, g_xy = sum h dx dy,
-      //   g_yy = sum h dy^2 with h = opacity*G*dL_dalpha;  g_op = sum h (= opacity * dL_dopacity);  g_r/g/b = sum alpha*T*dL_dpix
-      float g_mx = 0.f, g_my = 0.f, g_xx = 0.f, g_xy = 0.f, g_yy = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
-      bool any = false;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (mj & (1u << k)) {
-          const float dx = a.x - ((k & 1) ? pxf1 : pxf0), dy = a.y - ((k >> 1) ? pyf1 : pyf0);
-          const float alpha_raw = __builtin_amdgcn_exp2f(pair_p2(dx, dy, a.z, a.w, b.x, b.y));   // opacity * G
-          float alpha = alpha_raw;
-          if (mj & 16u) alpha = fminf(ALPHA_MAX, alpha);
-          const bool ok = (pos1 <= last[k]) && (alpha >= ALPHA_MIN);
-          if (ok) {
-            any = true;
-            const float rcp = __builtin_amdgcn_rcpf(1.0f - alpha);
-            T[k] *= rcp;                                   // transmittance in front of this instance
-            const float cd = fmaf(cb, dpb[k], fmaf(b.w, dpg[k], b.z * dpr[k]));   // c . dL_dpix
-            const float dch = alpha * T[k];
-            const float dL_dalpha = fmaf(T[k], cd, -Bk[k] * rcp);
-            Bk[k] = fmaf(cd, dch, Bk[k]);
-            g_r = fmaf(dch, dpr[k], g_r);
-            g_g = fmaf(dch, dpg[k], g_g);
-            g_b = fmaf(dch, dpb[k], g_b);
-            const float h = alpha_raw * dL_dalpha;      // opacity * G * dL_dalpha: the clamp passes the gradient on
-            g_op += h;                                     // (sum G dL_dalpha = this / opacity, applied to the row)
-            const float hx = h * dx, hy = h * dy;
-            g_mx += hx;                                    // first moments; the conic is applied per Gaussian
-            g_my += hy;                                    // by preprocess_bwd
-            g_xx = fmaf(hx, dx, g_xx);
-            g_xy = fmaf(hx, dy, g_xy);
-            g_yy = fmaf(hy, dy, g_yy);
-          }
-        }
-      }
-      if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-        const float s0 = wave_sum4(g_mx, g_xx, g_my, g_xy);   // rows: mx, my, xx, xy
-        const float s1 = wave_sum4(g_yy, g_r, g_op, g_g);     // rows: yy, op, r, g
-        const float s2 = wave_sum1_row3(g_b);                  // row 3: b
-        const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)slot, j);
-        const float inv_op_j = __builtin_amdgcn_exp2f(-b.y);     // 1 / opacity from the staged log2(opacity)
-        float* dst = reinterpret_cast<float*>(rows + sj);
-        if ((lane & 15) == 0) {
-          const int r = lane >> 4;
-          const float f0 = r < 2 ? 1.0f : (r == 2 ? -0.5f : -1.0f);
-          dst[r] = s0 * f0;                                    // Mx, My (first moments), dcxx, dcxy
-          const float f1 = r == 0 ? -0.5f : (r == 1 ? inv_op_j : 1.0f);
-          dst[4 + r] = s1 * f1;                                // dcyy, dop, dr, dg
-          if (r == 0) row_flags[sj] = 1;
-          if (r == 3) dst[8] = s2;
-        }
-      }
-    }
-  }
-}
-
-
 // ------------------------------------------------------------------------------------------------------------------
 // Backward, list-driven (the kernel that runs): one wave per tile, every 16-lane group (a DPP row) owns one 8x8
 // sub-block -- lane q of the group holds the 2x2 pixel quad (2 (q & 3), 2 (q >> 2)) of it -- and walks its OWN list of
 // the round's instances that reach the sub-block, back to front.  One wave instruction works on four different
-// (instance, sub-block) pairs, and the per-instance scalar control of the wave-per-instance loop above (mask read-out,
+// (instance, sub-block) pairs, and the per-instance scalar control of round 1's wave-per-instance loop (mask read-out,
 // four bit tests, EXEC juggling: 45 % of that kernel's time) is gone.  The nine sums of a pair are folded
 // over the 16-lane row with DPP only and added into the wave's LDS slab [instance][9], from which the staging lanes
 // write whole 48-byte rows at the end of the round.  Still no atomics, still bitwise reproducible: a slab word is
@@ -894,36 +687,23 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE, BWD_WAVES) void render_bwd_
                                                           const float* __restrict__ dL_dpix,
                                                           GradRow* __restrict__ rows,
                                                           uint8_t* __restrict__ row_flags) {
-#if !defined(GSR_BWD_CLASSIC)
   __shared__ SbLds sL[WAVES_PER_BLOCK];
-#else
-  __shared__ float4 sA[WAVES_PER_BLOCK][BATCH];
-  __shared__ float4 sB[WAVES_PER_BLOCK][BATCH];
-  __shared__ float sC[WAVES_PER_BLOCK][BATCH];
-#endif
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
   const int slot = blockIdx.x * WAVES_PER_BLOCK + wid;
   if (slot >= num_tiles) return;
   const int tile = __builtin_amdgcn_readfirstlane((int)tile_order[slot]);
-#if !defined(GSR_BWD_CLASSIC)
   render_bwd_tile_sb16(tile, sL[wid], W, H, grid_x, ranges, point_list, rec, slot_base, bg, final_T, n_contrib, tile_max,
                        dL_dpix, rows, row_flags);
-#else
-  render_bwd_tile(tile, sA[wid], sB[wid], sC[wid], W, H, grid_x, ranges, point_list, rec, slot_base, bg, final_T, n_contrib,
-                  tile_max, dL_dpix,
-                  rows, row_flags);
-#endif
 }
 
 void launch_render_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
                        const float* bg, float* out_color, float* final_T, uint32_t* n_contrib, uint32_t* tile_max,
-                       const uint32_t* tile_order, hipStream_t s, unsigned long long* stats) {
+                       const uint32_t* tile_order, hipStream_t s, unsigned long long* stats, int cull) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   const int nblk = gx * gy;       // one 256-lane workgroup per tile, longest list first
-  // debug switch for tests/test_gpu_miniblock_cull.py: with the cull off every staged instance enters all 16 lists;
-  // the image must not change by a bit (a dropped pair is a pair no pixel of which passes the alpha test)
-  const char* nc = getenv("GSR_DEBUG_NO_MINIBLOCK_CULL");
-  const int cull = (nc && nc[0] == '1') ? 0 : 1;
+  // cull = 0 (GsrParams.debug_flags & GSR_DEBUG_NO_MINIBLOCK_CULL, tests/test_gpu_miniblock_cull.py): every staged
+  // instance enters all 16 lists; the image must not change by a bit (a dropped pair is a pair no pixel of which
+  // passes the alpha test)
   if (stats)
     hipLaunchKernelGGL((render_fwd_kernel<true, true>), dim3(nblk), dim3(256), 0, s, W, H, gx, cull, tile_order, ranges,
                        point_list, rec, bg, out_color, final_T, n_contrib, tile_max, stats);

@@ -76,9 +76,14 @@ def l1_dssim_loss(network_output: torch.Tensor, gt: torch.Tensor, lambda_dssim: 
 
 @torch.no_grad()
 def add_densification_stats(model, viewspace_point_tensor: torch.Tensor, radii: torch.Tensor) -> None:
-    """``train.py:130-131`` in one kernel: for radii > 0 accumulate ||grad.xy||, count, track max radius."""
+    """``train.py:130-131`` in one kernel: for radii > 0 accumulate ||grad.xy||, count, track max radius.
+    A frame rendered with ``pipe.fuse_densify_stats`` has had them taken by its backward already."""
     lib = _lib.load()
     grad = viewspace_point_tensor.grad
+    if getattr(viewspace_point_tensor, "_gsr_stats_fused", False):
+        if grad is None:
+            raise ValueError("viewspace_points has no .grad (call backward first)")
+        return
     if grad is None:
         raise ValueError("viewspace_points has no .grad (call backward first)")
     if not grad.is_cuda:

@@ -5,10 +5,21 @@ with keyword arguments at ``:257-265``).  The arithmetic runs in ``libgsr_hip.so
 of ``include/gsr.h``; PyTorch only owns the memory and the stream.
 
 No CPU path exists: tensors must live on a ROCm device and the HIP library must be built.
+
+Host synchronisation.  Upstream reads ``num_rendered`` back in every forward to size its sort buffers.  Here only the
+first frame of a (device, P, W, H) combination does that (``gsr_forward_preprocess`` + ``gsr_forward_render``); later
+frames run ``gsr_forward`` with a caller-side capacity (1.5 x the largest instance count seen) and never stop the
+host.  The real count lands in pinned memory; it is compared with the capacity at the latest when the frame's
+backward starts, or when the next frame is issued -- a frame that overflowed raises ``GsrError`` there (its image
+and gradients are incomplete), and the capacity grows for the frames after it.  ``GSR_SYNC_FREE=0`` (read at import)
+or ``set_sync_free(False)`` keeps every frame on the two-call path.
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
+import os
+import threading
 from typing import NamedTuple, Optional
 
 import torch
@@ -65,31 +76,45 @@ def _require_gpu(t: torch.Tensor) -> torch.device:
     return t.device
 
 
+# ---- process-wide switches: read from the environment ONCE, at import; changed afterwards only through the setters ----
 _BINNING = {"keys64": _lib.BINNING_KEYS64, "two_level": _lib.BINNING_TWO_LEVEL, "culled": _lib.BINNING_TWO_LEVEL_CULLED}
 
 
-def _binning_mode() -> int:
-    """GSR_BINNING = culled (default: two_level minus the instances whose tile the alpha >= 1/255 ellipse cannot reach;
-    colour, radii and gradients are bit-identical to the other modes) | two_level (upstream's lists via two 32-bit
-    sorts) | keys64 (upstream's 64-bit (tile, depth) key sort)."""
-    import os
-    name = os.environ.get("GSR_BINNING", "culled").lower()
+def _binning_from_name(name: str) -> int:
+    name = name.lower()
     if name not in _BINNING:
-        raise ValueError(f"GSR_BINNING must be one of {sorted(_BINNING)}, got {name!r}")
+        raise ValueError(f"binning mode must be one of {sorted(_BINNING)}, got {name!r}")
     return _BINNING[name]
 
 
-_pinned = __import__("threading").local()
+_binning_mode_value = _binning_from_name(os.environ.get("GSR_BINNING", "culled"))
+_debug_flags_value = 0
+_sync_free_value = os.environ.get("GSR_SYNC_FREE", "1") != "0"
 
 
-def _counts_pinned() -> torch.Tensor:
-    """Per-thread pinned host buffer the scan kernel mirrors (num_rendered, num_visible) into: lets
-    gsr_forward_preprocess return as soon as the counts exist while the depth sort it enqueued keeps running."""
-    t = getattr(_pinned, "t", None)
-    if t is None:
-        t = torch.zeros(16, dtype=torch.int32).pin_memory()
-        _pinned.t = t
-    return t
+def set_binning_mode(name: str) -> str:
+    """culled (default: two_level minus the instances whose tile the alpha >= 1/255 ellipse cannot reach; colour, radii
+    and gradients are bit-identical to the other modes) | two_level (upstream's lists via two 32-bit sorts) | keys64
+    (upstream's 64-bit (tile, depth) key sort).  Initial value: GSR_BINNING at import.  Returns the previous name."""
+    global _binning_mode_value
+    prev = next(k for k, v in _BINNING.items() if v == _binning_mode_value)
+    _binning_mode_value = _binning_from_name(name)
+    return prev
+
+
+def set_debug_flags(flags: int) -> int:
+    """GsrParams.debug_flags for the calls that follow (``_lib.DEBUG_*``); returns the previous value."""
+    global _debug_flags_value
+    prev, _debug_flags_value = _debug_flags_value, int(flags)
+    return prev
+
+
+def set_sync_free(on: bool) -> bool:
+    """Whether frames after the first may run without the count read-back (module docstring); returns the previous
+    setting."""
+    global _sync_free_value
+    prev, _sync_free_value = _sync_free_value, bool(on)
+    return prev
 
 
 def _stream(dev: torch.device) -> int:
@@ -98,7 +123,7 @@ def _stream(dev: torch.device) -> int:
 
 def _make_params(dev, settings: GaussianRasterizationSettings, means3D, sh, colors_precomp, opacities, scales,
                  rotations, cov3Ds_precomp, sh_rest=None, act_flags: int = 0, forward_only: bool = False):
-    """Returns (GsrParams, keepalive list)."""
+    """Returns (GsrParams, keepalive list).  ``counts_pinned`` is left NULL: the forward paths below attach theirs."""
     bg = _f32c(settings.bg, "bg", dev)
     view = _f32c(settings.viewmatrix, "viewmatrix", dev)
     proj = _f32c(settings.projmatrix, "projmatrix", dev)
@@ -122,16 +147,237 @@ def _make_params(dev, settings: GaussianRasterizationSettings, means3D, sh, colo
     p.profile = _lib.active_profile_handle()      # raw handle; the owning object travels in ctx.profile
     p.shs_rest = _ptr(sh_rest)
     p.act_flags = int(act_flags)
-    p.binning_mode = _binning_mode()
-    p.counts_pinned = _counts_pinned().data_ptr()
+    p.binning_mode = _binning_mode_value
+    p.counts_pinned = None
     p.forward_only = int(bool(forward_only))
+    p.debug_flags = _debug_flags_value
     return p, [bg, view, proj, campos]
+
+
+def _round_ws(nbytes: int) -> int:
+    """Workspace sizes that depend on the per-view instance count are rounded up to 32 MiB steps, so that the caching
+    allocator reuses one block from frame to frame instead of growing a new size class per view."""
+    step = 1 << 25
+    return max(step, (int(nbytes) + step - 1) // step * step)
+
+
+# ---- deferred count check of the sync-free forward -----------------------------------------------------------------
+class _CapacityState:
+    """Per (device, P, W, H, binning mode): the instance capacity later frames are issued with."""
+    __slots__ = ("capacity", "last_counts")
+
+    def __init__(self):
+        self.capacity = 0
+        self.last_counts = (0, 0)
+
+    def observe(self, R: int, V: int) -> None:
+        self.last_counts = (R, V)
+        want = (int(R * 1.5) + (1 << 20)) >> 20 << 20       # 1.5 x, in steps of 2^20 instances
+        if R > 0 and want > self.capacity:
+            self.capacity = want
+
+
+class _Pending:
+    """One sync-free frame whose instance count has not been compared with its capacity yet."""
+    __slots__ = ("event", "slot", "capacity", "state", "done", "counts", "error")
+
+    def __init__(self, event, slot, capacity, state):
+        self.event, self.slot, self.capacity, self.state = event, slot, capacity, state
+        self.done, self.counts, self.error = False, None, None
+
+
+_MAX_STATES = 16
+_states: "collections.OrderedDict[tuple, _CapacityState]" = collections.OrderedDict()
+_pending: "collections.deque[_Pending]" = collections.deque()
+_free_slots: list = []
+_free_events: list = []
+_defer_lock = threading.RLock()
+
+
+def _state_for(key) -> _CapacityState:
+    with _defer_lock:
+        st = _states.get(key)
+        if st is None:
+            st = _states[key] = _CapacityState()
+            while len(_states) > _MAX_STATES:
+                _states.popitem(last=False)
+        else:
+            _states.move_to_end(key)
+        return st
+
+
+def _pinned_slot() -> torch.Tensor:
+    with _defer_lock:
+        if _free_slots:
+            return _free_slots.pop()
+    return torch.zeros(16, dtype=torch.int32).pin_memory()
+
+
+def _new_event() -> int:
+    with _defer_lock:
+        if _free_events:
+            return _free_events.pop()
+    ev = C.c_void_p()
+    _lib.check(_lib.load().gsr_event_create(C.byref(ev)), "gsr_event_create")
+    return ev.value
+
+
+def _verify(pend: _Pending, block: bool) -> bool:
+    """Compare the frame's real instance count with the capacity it ran with (waits for the scan kernel of that frame
+    when ``block``).  Raises GsrError for an overflowed frame -- every time it is asked about."""
+    with _defer_lock:
+        if not pend.done:
+            lib = _lib.load()
+            if block:
+                _lib.check(lib.gsr_event_wait(pend.event), "gsr_event_wait")
+            else:
+                done = C.c_int32(0)
+                _lib.check(lib.gsr_event_query(pend.event, C.byref(done)), "gsr_event_query")
+                if not done.value:
+                    return False
+            R, V = int(pend.slot[0]) & 0xffffffff, int(pend.slot[1]) & 0xffffffff
+            pend.done, pend.counts = True, (R, V)
+            pend.state.observe(R, V)
+            _free_slots.append(pend.slot)
+            _free_events.append(pend.event)
+            pend.slot = pend.event = None
+            try:
+                _pending.remove(pend)
+            except ValueError:
+                pass
+            if R > pend.capacity:
+                pend.error = (f"frame issued without a count read-back overflowed its binning capacity: {R} instances > "
+                              f"capacity {pend.capacity}; its image and gradients are incomplete and must be discarded "
+                              "(later frames get a larger capacity; set_sync_free(False) / GSR_SYNC_FREE=0 restores the "
+                              "per-frame read-back)")
+        if pend.error:
+            raise _lib.GsrError(pend.error)
+        return True
+
+
+def _drain_pending(block: bool = False) -> None:
+    """Check every earlier sync-free frame whose count has arrived (all of them when ``block``)."""
+    while True:
+        with _defer_lock:
+            pend = _pending[0] if _pending else None
+        if pend is None or not _verify(pend, block):
+            return
+
+
+def synchronize_counts() -> None:
+    """Block until every frame issued so far has had its instance count checked; raises GsrError if one overflowed.
+    Call it before trusting the image of a forward-only frame (e.g. before writing it to disk)."""
+    _drain_pending(block=True)
+
+
+def last_counts(dev, P: int, W: int, H: int) -> tuple:
+    """(num_rendered, num_visible) of the most recent checked frame of that shape on ``dev`` ((0, 0) if none)."""
+    key = (torch.device(dev).index or 0, int(P), int(W), int(H), _binning_mode_value)
+    with _defer_lock:
+        st = _states.get(key)
+        return st.last_counts if st is not None else (0, 0)
+
+
+_two_call_pinned = threading.local()
+
+
+def _counts_pinned_two_call() -> torch.Tensor:
+    """Per-thread pinned host buffer the scan kernel mirrors (num_rendered, num_visible, depth range) into: lets
+    gsr_forward_preprocess return as soon as the counts exist while the depth sort it enqueued keeps running."""
+    t = getattr(_two_call_pinned, "t", None)
+    if t is None:
+        t = torch.zeros(16, dtype=torch.int32).pin_memory()
+        _two_call_pinned.t = t
+    return t
+
+
+class _Frame(NamedTuple):
+    """What a forward leaves behind for its backward."""
+    geom: torch.Tensor
+    binning: torch.Tensor
+    img: torch.Tensor
+    radii: torch.Tensor
+    layout_R: int          # (num_rendered, num_visible) the workspaces are laid out for: the real counts after the
+    layout_V: int          #  two-call forward, (capacity, P) after the sync-free one
+    pending: Optional[_Pending]
+
+
+def _run_forward(lib, dev, params, P: int, W: int, H: int):
+    """Native forward on torch's current stream.  Returns (color, _Frame)."""
+    stream = _stream(dev)
+    geom = torch.empty(lib.gsr_geom_bytes(P), dtype=torch.uint8, device=dev)
+    img = torch.empty(lib.gsr_image_bytes(W, H), dtype=torch.uint8, device=dev)
+    radii = torch.empty(P, dtype=torch.int32, device=dev)      # written for every Gaussian by the kernel
+    color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+    mode = params.binning_mode
+    st = _state_for((dev.index or 0, P, W, H, mode))
+    _drain_pending()
+    if _sync_free_value and st.capacity > 0 and mode != _lib.BINNING_KEYS64 and P > 0:
+        cap = st.capacity
+        slot, event = _pinned_slot(), _new_event()
+        params.counts_pinned = slot.data_ptr()
+        nbytes = lib.gsr_binning_bytes(cap, P, W, H, mode)
+        binning = torch.empty(_round_ws(nbytes), dtype=torch.uint8, device=dev)
+        pend = _Pending(event, slot, cap, st)
+        with _defer_lock:
+            _pending.append(pend)
+        _lib.check(lib.gsr_forward(C.byref(params), geom.data_ptr(), binning.data_ptr(), nbytes, cap, img.data_ptr(),
+                                   radii.data_ptr(), color.data_ptr(), event, stream), "gsr_forward")
+        return color, _Frame(geom, binning, img, radii, cap, P, pend)
+    pinned = _counts_pinned_two_call()
+    params.counts_pinned = pinned.data_ptr()
+    num_rendered, num_visible = C.c_uint32(0), C.c_uint32(0)
+    _lib.check(lib.gsr_forward_preprocess(C.byref(params), geom.data_ptr(), _ptr(radii), stream,
+                                          C.byref(num_rendered), C.byref(num_visible)), "gsr_forward_preprocess")
+    R, V = int(num_rendered.value), int(num_visible.value)
+    st.observe(R, V)
+    nbytes = lib.gsr_binning_bytes(R, V, W, H, mode)
+    binning = torch.empty(_round_ws(nbytes), dtype=torch.uint8, device=dev)
+    _lib.check(lib.gsr_forward_render(C.byref(params), geom.data_ptr(), binning.data_ptr(), nbytes, img.data_ptr(),
+                                      R, V, color.data_ptr(), stream), "gsr_forward_render")
+    return color, _Frame(geom, binning, img, radii, R, V, None)
+
+
+def _run_backward(lib, dev, params, frame: _Frame, grad_out_color: torch.Tensor, grads: "_lib.GsrGrads") -> None:
+    if frame.pending is not None:
+        _verify(frame.pending, block=True)      # the scan kernel of this frame's forward finished long ago
+    P = int(params.P)
+    nbytes = lib.gsr_backward_bytes(P, frame.layout_R)
+    bwd_ws = torch.empty(_round_ws(nbytes), dtype=torch.uint8, device=dev)
+    _lib.check(lib.gsr_backward(C.byref(params), _ptr(frame.radii), frame.geom.data_ptr(), frame.binning.data_ptr(),
+                                frame.img.data_ptr(), frame.layout_R, frame.layout_V, grad_out_color.data_ptr(),
+                                bwd_ws.data_ptr(), nbytes, C.byref(grads), _stream(dev)), "gsr_backward")
+
+
+def frame_counts(color: torch.Tensor) -> tuple:
+    """(num_rendered, num_visible) of the frame that produced ``color`` (an output of the operator that still carries
+    its autograd node).  Waits for the count of a frame that ran without the read-back; raises if it overflowed."""
+    ctx = color.grad_fn
+    if ctx is None or not hasattr(ctx, "frame_pending"):
+        raise ValueError("not an output of the rasterizer with an autograd node (rendered under no_grad?)")
+    pend = ctx.frame_pending
+    if pend is not None:
+        _verify(pend, block=True)
+        return pend.counts
+    return ctx.layout
+
+
+def _stats_ptrs(stats, P: int, dev):
+    """(accum, denom, max_radii2D) pointers of the fused densification statistics, or three Nones."""
+    if stats is None:
+        return None, None, None
+    out = []
+    for t in stats:
+        if not (t.is_cuda and t.device == dev and t.is_contiguous() and t.dtype == torch.float32 and t.numel() == P):
+            raise TypeError("densification accumulators must be contiguous float32 GPU tensors with one element per Gaussian")
+        out.append(t.data_ptr())
+    return tuple(out)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings: GaussianRasterizationSettings, forward_only: bool = False):
+                raster_settings: GaussianRasterizationSettings, forward_only: bool = False, stats=None):
         lib = _lib.load()
         dev = _require_gpu(means3D)
         P = int(means3D.shape[0])
@@ -157,21 +403,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         with torch.cuda.device(dev):
             params, keep = _make_params(dev, raster_settings, means3D, sh, colors_precomp, opacities, scales,
                                         rotations, cov3Ds_precomp, forward_only=forward_only)
-            stream = _stream(dev)
-            geom = torch.empty(lib.gsr_geom_bytes(P), dtype=torch.uint8, device=dev)
-            img = torch.empty(lib.gsr_image_bytes(W, H), dtype=torch.uint8, device=dev)
-            radii = torch.empty(P, dtype=torch.int32, device=dev)      # written for every Gaussian by the kernel
-            color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
-            num_rendered, num_visible = C.c_uint32(0), C.c_uint32(0)
             try:
-                _lib.check(lib.gsr_forward_preprocess(C.byref(params), geom.data_ptr(), _ptr(radii), stream,
-                                                      C.byref(num_rendered), C.byref(num_visible)),
-                           "gsr_forward_preprocess")
-                R, V = int(num_rendered.value), int(num_visible.value)
-                nbytes = lib.gsr_binning_bytes(R, V, W, H, params.binning_mode)
-                binning = torch.empty(_round_ws(nbytes), dtype=torch.uint8, device=dev)
-                _lib.check(lib.gsr_forward_render(C.byref(params), geom.data_ptr(), binning.data_ptr(), nbytes,
-                                                  img.data_ptr(), R, V, color.data_ptr(), stream), "gsr_forward_render")
+                color, frame = _run_forward(lib, dev, params, P, W, H)
             except _lib.GsrError:
                 if raster_settings.debug:
                     torch.save((means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -181,14 +414,15 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         ctx.raster_settings = raster_settings
         ctx.profile = _lib.active_profile()     # backward runs on an autograd thread: carry the (live) object explicitly
-        ctx.num_rendered = R
-        ctx.num_visible = V
+        ctx.layout = (frame.layout_R, frame.layout_V)
+        ctx.frame_pending = frame.pending
         ctx.binning_mode = params.binning_mode
+        ctx.stats = stats
         ctx.keep = keep
-        ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, geom,
-                              binning, img)
-        ctx.mark_non_differentiable(radii)
-        return color, radii
+        ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, frame.radii,
+                              frame.geom, frame.binning, frame.img)
+        ctx.mark_non_differentiable(frame.radii)
+        return color, frame.radii
 
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii):
@@ -198,7 +432,6 @@ class _RasterizeGaussians(torch.autograd.Function):
         settings = ctx.raster_settings
         dev = means3D.device
         P = int(means3D.shape[0])
-        R = ctx.num_rendered
         grad_out_color = _f32c(grad_out_color, "grad_out_color", dev, align16=True)
 
         with torch.cuda.device(dev):
@@ -206,7 +439,6 @@ class _RasterizeGaussians(torch.autograd.Function):
                                         cov3Ds_precomp)
             params.profile = ctx.profile.handle() if ctx.profile is not None else None
             params.binning_mode = ctx.binning_mode
-            stream = _stream(dev)
             new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
             g_means3D, g_means2D, g_opac = new(P, 3), new(P, 3), new(*opacities.shape)
             g_sh = new(*sh.shape) if sh.numel() else None
@@ -215,13 +447,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_rot = new(P, 4) if rotations.numel() else None
             g_cov = new(P, 6) if cov3Ds_precomp.numel() else None
             grads = _lib.GsrGrads(_ptr(g_means3D), _ptr(g_means2D), _ptr(g_sh), _ptr(g_col), _ptr(g_opac),
-                                  _ptr(g_scales), _ptr(g_rot), _ptr(g_cov), None)
-            nbytes = lib.gsr_backward_bytes(P, R)
-            bwd_ws = torch.empty(_round_ws(nbytes), dtype=torch.uint8, device=dev)
+                                  _ptr(g_scales), _ptr(g_rot), _ptr(g_cov), None, *_stats_ptrs(ctx.stats, P, dev))
+            frame = _Frame(geom, binning, img, radii, ctx.layout[0], ctx.layout[1], ctx.frame_pending)
             try:
-                _lib.check(lib.gsr_backward(C.byref(params), _ptr(radii), geom.data_ptr(), binning.data_ptr(),
-                                            img.data_ptr(), R, ctx.num_visible, grad_out_color.data_ptr(), bwd_ws.data_ptr(), nbytes,
-                                            C.byref(grads), stream), "gsr_backward")
+                _run_backward(lib, dev, params, frame, grad_out_color, grads)
             except _lib.GsrError:
                 if settings.debug:
                     torch.save((means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii,
@@ -229,7 +458,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise
         del keep
-        return g_means3D, g_means2D, g_sh, g_col, g_opac, g_scales, g_rot, g_cov, None, None
+        return g_means3D, g_means2D, g_sh, g_col, g_opac, g_scales, g_rot, g_cov, None, None, None
 
 
 class _RasterizeGaussiansFused(torch.autograd.Function):
@@ -240,7 +469,7 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations,
-                raster_settings: GaussianRasterizationSettings, forward_only: bool = False):
+                raster_settings: GaussianRasterizationSettings, forward_only: bool = False, stats=None):
         lib = _lib.load()
         dev = _require_gpu(means3D)
         P = int(means3D.shape[0])
@@ -264,29 +493,26 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
         with torch.cuda.device(dev):
             params, keep = _make_params(dev, raster_settings, means3D, f_dc, empty, raw_opacity, raw_scales,
                                         raw_rotations, empty, sh_rest=f_rest, act_flags=flags, forward_only=forward_only)
-            stream = _stream(dev)
-            geom = torch.empty(lib.gsr_geom_bytes(P), dtype=torch.uint8, device=dev)
-            img = torch.empty(lib.gsr_image_bytes(W, H), dtype=torch.uint8, device=dev)
-            radii = torch.empty(P, dtype=torch.int32, device=dev)      # written for every Gaussian by the kernel
-            color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
-            num_rendered, num_visible = C.c_uint32(0), C.c_uint32(0)
-            _lib.check(lib.gsr_forward_preprocess(C.byref(params), geom.data_ptr(), _ptr(radii), stream,
-                                                  C.byref(num_rendered), C.byref(num_visible)), "gsr_forward_preprocess")
-            R, V = int(num_rendered.value), int(num_visible.value)
-            nbytes = lib.gsr_binning_bytes(R, V, W, H, params.binning_mode)
-            binning = torch.empty(_round_ws(nbytes), dtype=torch.uint8, device=dev)
-            _lib.check(lib.gsr_forward_render(C.byref(params), geom.data_ptr(), binning.data_ptr(), nbytes,
-                                              img.data_ptr(), R, V, color.data_ptr(), stream), "gsr_forward_render")
+            try:
+                color, frame = _run_forward(lib, dev, params, P, W, H)
+            except _lib.GsrError:
+                if raster_settings.debug:      # same snapshot convention as the getter-fed operator above
+                    torch.save((means3D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations, tuple(raster_settings)),
+                               "snapshot_fw.dump")
+                    print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise
         ctx.raster_settings = raster_settings
         ctx.profile = _lib.active_profile()
-        ctx.num_rendered = R
-        ctx.num_visible = V
+        ctx.layout = (frame.layout_R, frame.layout_V)
+        ctx.frame_pending = frame.pending
         ctx.binning_mode = params.binning_mode
         ctx.act_flags = flags
+        ctx.stats = stats
         ctx.keep = keep
-        ctx.save_for_backward(means3D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations, radii, geom, binning, img)
-        ctx.mark_non_differentiable(radii)
-        return color, radii
+        ctx.save_for_backward(means3D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations, frame.radii, frame.geom,
+                              frame.binning, frame.img)
+        ctx.mark_non_differentiable(frame.radii)
+        return color, frame.radii
 
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii):
@@ -295,7 +521,6 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
         settings = ctx.raster_settings
         dev = means3D.device
         P = int(means3D.shape[0])
-        R = ctx.num_rendered
         grad_out_color = _f32c(grad_out_color, "grad_out_color", dev, align16=True)
         empty = torch.empty(0, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
@@ -303,27 +528,23 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
                                         empty, sh_rest=f_rest, act_flags=ctx.act_flags)
             params.profile = ctx.profile.handle() if ctx.profile is not None else None
             params.binning_mode = ctx.binning_mode
-            stream = _stream(dev)
             new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
             g_means3D, g_means2D = new(P, 3), new(P, 3)
             g_dc, g_rest = new(*f_dc.shape), new(*f_rest.shape)
             g_opac, g_scales, g_rot = new(*raw_opacity.shape), new(P, 3), new(P, 4)
             grads = _lib.GsrGrads(_ptr(g_means3D), _ptr(g_means2D), _ptr(g_dc), None, _ptr(g_opac), _ptr(g_scales),
-                                  _ptr(g_rot), None, _ptr(g_rest))
-            nbytes = lib.gsr_backward_bytes(P, R)
-            bwd_ws = torch.empty(_round_ws(nbytes), dtype=torch.uint8, device=dev)
-            _lib.check(lib.gsr_backward(C.byref(params), _ptr(radii), geom.data_ptr(), binning.data_ptr(),
-                                        img.data_ptr(), R, ctx.num_visible, grad_out_color.data_ptr(), bwd_ws.data_ptr(), nbytes,
-                                        C.byref(grads), stream), "gsr_backward")
+                                  _ptr(g_rot), None, _ptr(g_rest), *_stats_ptrs(ctx.stats, P, dev))
+            frame = _Frame(geom, binning, img, radii, ctx.layout[0], ctx.layout[1], ctx.frame_pending)
+            try:
+                _run_backward(lib, dev, params, frame, grad_out_color, grads)
+            except _lib.GsrError:
+                if settings.debug:
+                    torch.save((means3D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations, radii, grad_out_color,
+                                tuple(settings)), "snapshot_bw.dump")
+                    print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise
         del keep
-        return g_means3D, g_means2D, g_dc, g_rest, g_opac, g_scales, g_rot, None, None
-
-
-def _round_ws(nbytes: int) -> int:
-    """Workspace sizes that depend on the per-view instance count are rounded up to 32 MiB steps, so that the caching
-    allocator reuses one block from frame to frame instead of growing a new size class per view."""
-    step = 1 << 25
-    return max(step, (int(nbytes) + step - 1) // step * step)
+        return g_means3D, g_means2D, g_dc, g_rest, g_opac, g_scales, g_rot, None, None, None
 
 
 def _forward_only(*tensors) -> bool:
@@ -331,17 +552,20 @@ def _forward_only(*tensors) -> bool:
     return not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors))
 
 
-def rasterize_gaussians_fused(means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations, raster_settings):
+def rasterize_gaussians_fused(means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations, raster_settings,
+                              densify_stats=None):
+    """``densify_stats``: None, or (xyz_gradient_accum, denom, max_radii2D) -- the backward then also accumulates the
+    densification statistics of ``scene/gaussian_model.py:775-777`` / ``train.py:130``."""
     fo = _forward_only(means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations)
     return _RasterizeGaussiansFused.apply(means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations,
-                                          raster_settings, fo)
+                                          raster_settings, fo, densify_stats)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings):
+                        raster_settings, densify_stats=None):
     fo = _forward_only(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, fo)
+                                     cov3Ds_precomp, raster_settings, fo, densify_stats)
 
 
 class GaussianRasterizer(nn.Module):
@@ -365,7 +589,7 @@ class GaussianRasterizer(nn.Module):
         return vis.bool()
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None):
+                cov3D_precomp=None, densify_stats=None):
         raster_settings = self.raster_settings
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
@@ -379,9 +603,9 @@ class GaussianRasterizer(nn.Module):
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3D_precomp, raster_settings)
+                                   cov3D_precomp, raster_settings, densify_stats)
 
-    def forward_fused(self, means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations):
+    def forward_fused(self, means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations, densify_stats=None):
         """Raw-parameter entry: see :class:`_RasterizeGaussiansFused`."""
         return rasterize_gaussians_fused(means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations,
-                                         self.raster_settings)
+                                         self.raster_settings, densify_stats)

@@ -46,10 +46,27 @@ def _zero_leaf(like: torch.Tensor) -> torch.Tensor:
     return z.detach().requires_grad_(True)
 
 
+def _fused_stats(pc, pipe, xyz):
+    """(xyz_gradient_accum, denom, max_radii2D) when the caller asked for the densification statistics to be taken
+    inside the backward (``pipe.fuse_densify_stats``) and the model carries float32 accumulators."""
+    if not getattr(pipe, "fuse_densify_stats", False) or not (torch.is_grad_enabled() and xyz.requires_grad):
+        return None
+    trio = tuple(getattr(pc, k, None) for k in ("xyz_gradient_accum", "denom", "max_radii2D"))
+    P = int(xyz.shape[0])
+    if any(t is None or not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != P for t in trio):
+        return None
+    return trio
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier: float = 1.0,
            override_color=None, **_fork_kwargs):
     """Render the scene; ``bg_color`` must be on the GPU.  Returns the reference's result dict
-    (``gaussian_renderer/__init__.py:309-313``)."""
+    (``gaussian_renderer/__init__.py:309-313``).
+
+    ``pipe.fuse_densify_stats = True`` (this build's extension) makes the backward of this frame also run
+    ``add_densification_stats`` (``scene/gaussian_model.py:775-777``) and the ``max_radii2D`` update of ``train.py:130``
+    on the model's accumulators; the ``add_densification_stats`` of this package then recognises the frame and does
+    nothing, so the reference's call sequence (render, backward, add_densification_stats) stays as it is."""
     xyz = pc.get_xyz
     # zero tensor whose .grad receives dL/d(mean2D) for the densification statistics.  The reference builds it as
     # `zeros_like(...) + 0` + retain_grad() (gaussian_renderer/__init__.py:32-36); a leaf with requires_grad gets
@@ -57,6 +74,9 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier:
     # The operator never reads (or writes) its values, so every frame's leaf aliases one cached block of zeros: a
     # fresh 72 MB memset per frame is 20 us of the 6 M-Gaussian forward.
     screenspace_points = _zero_leaf(xyz)
+    stats = _fused_stats(pc, pipe, xyz)
+    if stats is not None:
+        screenspace_points._gsr_stats_fused = True      # read by losses.add_densification_stats
 
     raster_settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height),
@@ -77,7 +97,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier:
     if _can_fuse(pc, pipe, override_color):
         # same result as the getter path below, without materialising cat(f_dc, f_rest), exp, normalize, sigmoid
         rendered_image, radii = rasterizer.forward_fused(xyz, screenspace_points, pc._features_dc, pc._features_rest,
-                                                         pc._opacity, pc._scaling, pc._rotation)
+                                                         pc._opacity, pc._scaling, pc._rotation, densify_stats=stats)
         return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
                 "radii": radii, "selected_pts_mask": None}
 
@@ -102,7 +122,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier:
 
     rendered_image, radii = rasterizer(means3D=xyz, means2D=screenspace_points, shs=shs,
                                        colors_precomp=colors_precomp, opacities=pc.get_opacity, scales=scales,
-                                       rotations=rotations, cov3D_precomp=cov3D_precomp)
+                                       rotations=rotations, cov3D_precomp=cov3D_precomp, densify_stats=stats)
     return {"render": rendered_image,
             "viewspace_points": screenspace_points,
             "visibility_filter": radii > 0,

@@ -181,6 +181,7 @@ class PipelineParams:
     compute_cov3D_python = False
     debug = False
     fuse_activations = True     # this build's extension: feed raw parameters to the operator when possible
+    fuse_densify_stats = False  # this build's extension: the backward also takes the densification statistics
 
 
 def make_scene(cfg: SceneConfig, seed: int = 0, device="cpu", P: Optional[int] = None, view: int = 0,

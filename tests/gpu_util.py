@@ -18,8 +18,9 @@ def product_settings(cam, bg, sh_degree, dev, scale_modifier=1.0, debug=False):
 
 
 def forward_with_state(dev, settings, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                       cov3D_precomp=None, binning_mode=None, want_stats=False):
-    """Forward through the C ABI keeping the workspaces; returns a dict of numpy/torch results."""
+                       cov3D_precomp=None, binning_mode=None, want_stats=False, sync_free_capacity=None):
+    """Forward through the C ABI keeping the workspaces; returns a dict of numpy/torch results.
+    sync_free_capacity: run gsr_forward (no count read-back) with that instance capacity instead of the two calls."""
     lib = _lib.load()
     e = torch.empty(0, dtype=torch.float32, device=dev)
     f = lambda t: e if t is None else t.to(dev).float().contiguous()  # noqa: E731
@@ -37,13 +38,27 @@ def forward_with_state(dev, settings, means3D, opacities, shs=None, colors_preco
         R, V = C.c_uint32(0), C.c_uint32(0)
         # the list-level parity tests speak about the un-culled lists unless a mode is asked for
         params.binning_mode = _lib.BINNING_TWO_LEVEL if binning_mode is None else binning_mode
-        _lib.check(lib.gsr_forward_preprocess(C.byref(params), geom.data_ptr(), radii.data_ptr(), stream, C.byref(R),
-                                              C.byref(V)), "pre")
-        R, V = int(R.value), int(V.value)
-        nb = lib.gsr_binning_bytes(R, V, W, H, params.binning_mode)
-        binning = torch.empty(nb, dtype=torch.uint8, device=dev)
-        _lib.check(lib.gsr_forward_render(C.byref(params), geom.data_ptr(), binning.data_ptr(), nb, img.data_ptr(), R, V,
-                                          color.data_ptr(), stream), "render")
+        if sync_free_capacity is None:
+            _lib.check(lib.gsr_forward_preprocess(C.byref(params), geom.data_ptr(), radii.data_ptr(), stream, C.byref(R),
+                                                  C.byref(V)), "pre")
+            R, V = int(R.value), int(V.value)
+            nb = lib.gsr_binning_bytes(R, V, W, H, params.binning_mode)
+            binning = torch.empty(nb, dtype=torch.uint8, device=dev)
+            _lib.check(lib.gsr_forward_render(C.byref(params), geom.data_ptr(), binning.data_ptr(), nb, img.data_ptr(), R, V,
+                                              color.data_ptr(), stream), "render")
+            lay_R, lay_V = R, V
+        else:
+            cap = int(sync_free_capacity)
+            pinned = torch.zeros(16, dtype=torch.int32).pin_memory()
+            params.counts_pinned = pinned.data_ptr()
+            nb = lib.gsr_binning_bytes(cap, P, W, H, params.binning_mode)
+            binning = torch.empty(nb, dtype=torch.uint8, device=dev)
+            _lib.check(lib.gsr_forward(C.byref(params), geom.data_ptr(), binning.data_ptr(), nb, cap, img.data_ptr(),
+                                       radii.data_ptr(), color.data_ptr(), None, stream), "gsr_forward")
+            torch.cuda.synchronize(dev)
+            R, V = int(pinned[0]) & 0xffffffff, int(pinned[1]) & 0xffffffff
+            assert R <= cap, "test asked for a capacity below the instance count"
+            lay_R, lay_V = cap, P       # what the workspaces are laid out for
         xy = torch.empty(P, 2, device=dev)
         con = torch.empty(P, 4, device=dev)
         rgb = torch.empty(P, 3, device=dev)
@@ -57,8 +72,14 @@ def forward_with_state(dev, settings, means3D, opacities, shs=None, colors_preco
                                            clamped.data_ptr(), stream), "read_geom")
         keys = torch.empty(max(R, 1), dtype=torch.int64, device=dev)
         plist = torch.empty(max(R, 1), dtype=torch.int32, device=dev)
-        _lib.check(lib.gsr_debug_read_binning(geom.data_ptr(), P, binning.data_ptr(), R, V, W, H, params.binning_mode,
-                                              keys.data_ptr(), plist.data_ptr(), stream), "read_bin")
+        if lay_R != R:       # capacity-sized layout: the debug reader copies R_layout entries; read into capacity-sized buffers
+            keys_l = torch.empty(max(lay_R, 1), dtype=torch.int64, device=dev)
+            plist_l = torch.empty(max(lay_R, 1), dtype=torch.int32, device=dev)
+        else:
+            keys_l, plist_l = keys, plist
+        _lib.check(lib.gsr_debug_read_binning(geom.data_ptr(), P, binning.data_ptr(), lay_R, lay_V, W, H, params.binning_mode,
+                                              keys_l.data_ptr(), plist_l.data_ptr(), stream), "read_bin")
+        keys, plist = keys_l, plist_l
         gx, gy = (W + 15) // 16, (H + 15) // 16
         final_T = torch.empty(H, W, device=dev)
         n_contrib = torch.empty(H, W, dtype=torch.int32, device=dev)
@@ -69,7 +90,7 @@ def forward_with_state(dev, settings, means3D, opacities, shs=None, colors_preco
         if want_stats and R > 0:      # work counters of the forward compositing kernel (re-runs it with counting on)
             st8 = torch.zeros(8, dtype=torch.int64, device=dev)
             scratch = torch.empty_like(color)
-            _lib.check(lib.gsr_debug_render_stats(C.byref(params), geom.data_ptr(), binning.data_ptr(), img.data_ptr(), R, V,
+            _lib.check(lib.gsr_debug_render_stats(C.byref(params), geom.data_ptr(), binning.data_ptr(), img.data_ptr(), lay_R, lay_V,
                                                   scratch.data_ptr(), st8.data_ptr(), stream), "stats")
             torch.cuda.synchronize(dev)
             v = st8.cpu().tolist()

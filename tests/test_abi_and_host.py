@@ -39,8 +39,9 @@ def test_struct_layouts_match_the_c_compiler():
 #include <stddef.h>
 #include "gsr.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %d\n", sizeof(GsrParams), sizeof(GsrGrads), offsetof(GsrParams, means3D),
-         offsetof(GsrParams, bg), offsetof(GsrParams, counts_pinned), offsetof(GsrGrads, dL_dshs_rest), GSR_STAGE_COUNT);
+  printf("%zu %zu %zu %zu %zu %zu %d %zu %zu %d\n", sizeof(GsrParams), sizeof(GsrGrads), offsetof(GsrParams, means3D),
+         offsetof(GsrParams, bg), offsetof(GsrParams, counts_pinned), offsetof(GsrGrads, dL_dshs_rest), GSR_STAGE_COUNT,
+         offsetof(GsrParams, debug_flags), offsetof(GsrGrads, stats_max_radii2D), GSR_ABI_VERSION);
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -52,7 +53,7 @@ int main(void) {
     vals = list(map(int, out))
     P, G = _lib.GsrParams, _lib.GsrGrads
     assert vals == [C.sizeof(P), C.sizeof(G), P.means3D.offset, P.bg.offset, P.counts_pinned.offset, G.dL_dshs_rest.offset,
-                    _lib.STAGE_COUNT]
+                    _lib.STAGE_COUNT, P.debug_flags.offset, G.stats_max_radii2D.offset, _lib.ABI_VERSION]
 
 
 def test_workspace_sizes_are_monotone_and_aligned():
@@ -83,6 +84,12 @@ def test_bad_arguments_are_rejected_before_any_launch():
     assert lib.gsr_forward_preprocess(None, None, None, None, C.byref(n), C.byref(n)) == -1
     p.width = 0
     assert lib.gsr_forward_preprocess(C.byref(p), None, None, None, C.byref(n), C.byref(n)) == -1
+    # the sync-free entry point: same validation, plus its own preconditions (all refused before any HIP call)
+    assert lib.gsr_forward(None, None, None, 0, 1, None, None, None, None, None) == -1
+    p.width = 64
+    assert lib.gsr_forward(C.byref(p), None, None, 0, 1, None, None, None, None, None) == -1
+    assert lib.gsr_event_wait(None) == -1 and lib.gsr_event_query(None, None) == -1
+    assert lib.gsr_event_destroy(None) == 0
 
 
 def _cpu_call(**over):
@@ -136,15 +143,17 @@ def test_missing_library_is_a_loud_error(monkeypatch):
         _lib.load()
 
 
-def test_binning_mode_selection_from_environment(monkeypatch):
-    from mvs_gaussian_splatting_amd import _lib
-    from mvs_gaussian_splatting_amd.rasterizer import _binning_mode
-    monkeypatch.delenv("GSR_BINNING", raising=False)
-    assert _binning_mode() == _lib.BINNING_TWO_LEVEL_CULLED
+def test_binning_mode_selection(monkeypatch):
+    """The mode is a module setting handed to the library in GsrParams.binning_mode (GSR_BINNING only seeds it at
+    import): no per-call environment reads on the hot path."""
+    from mvs_gaussian_splatting_amd import _lib, rasterizer
+    monkeypatch.setattr(rasterizer, "_binning_mode_value", _lib.BINNING_TWO_LEVEL_CULLED)
     for name, val in (("keys64", _lib.BINNING_KEYS64), ("two_level", _lib.BINNING_TWO_LEVEL), ("CULLED", _lib.BINNING_TWO_LEVEL_CULLED)):
-        monkeypatch.setenv("GSR_BINNING", name)
-        assert _binning_mode() == val
-    monkeypatch.setenv("GSR_BINNING", "fastest")
-    import pytest
+        rasterizer.set_binning_mode(name)
+        assert rasterizer._binning_mode_value == val
+    assert rasterizer.set_binning_mode("culled") == "culled"
     with pytest.raises(ValueError):
-        _binning_mode()
+        rasterizer.set_binning_mode("fastest")
+    src = open(rasterizer.__file__).read()
+    body = src[src.index("def _make_params"):]
+    assert "os.environ" not in body, "no environment reads after import"

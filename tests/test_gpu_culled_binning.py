@@ -102,7 +102,8 @@ def test_culled_binning_on_the_rare_branch_scene(dev):
 def _train_step(dev, monkeypatch, mode, model, cam, bg, target, fused):
     from mvs_gaussian_splatting_amd import render, l1_loss
     from mvs_gaussian_splatting_amd.synthetic import PipelineParams
-    monkeypatch.setenv("GSR_BINNING", mode)
+    from mvs_gaussian_splatting_amd import rasterizer
+    monkeypatch.setattr(rasterizer, "_binning_mode_value", rasterizer._binning_from_name(mode))
     for p in model.parameters():
         p.grad = None
     pipe = PipelineParams()
@@ -110,7 +111,7 @@ def _train_step(dev, monkeypatch, mode, model, cam, bg, target, fused):
     pkg = render(cam, model, pipe, bg)
     l1_loss(pkg["render"], target).backward()
     return (pkg["render"].detach().clone(), pkg["radii"].clone(), pkg["viewspace_points"].grad.detach().clone(),
-            [p.grad.detach().clone() for p in model.parameters()], int(pkg["render"].grad_fn.num_rendered))
+            [p.grad.detach().clone() for p in model.parameters()], int(rasterizer.frame_counts(pkg["render"])[0]))
 
 
 @pytest.mark.parametrize("fused", [True, False])

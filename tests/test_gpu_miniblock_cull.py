@@ -1,6 +1,6 @@
 """The forward's 4x4 mini-block visit lists: an (instance, mini-block) pair is dropped only when
 every pixel of the mini-block fails alpha >= 1/255 in the evaluation's own float32 arithmetic.  With the cull switched
-off (GSR_DEBUG_NO_MINIBLOCK_CULL=1: every staged instance enters all 16 lists of its tile) the colour, the final
+off (GsrParams.debug_flags & GSR_DEBUG_NO_MINIBLOCK_CULL: every staged instance enters all 16 lists of its tile) the colour, the final
 transmittance and the last-contributor index of every pixel must be BIT-IDENTICAL -- on random clouds, on the
 rare-branch soup (screen-filling, sub-pixel, needle, guard-band, near-plane, opaque and transparent Gaussians) and on
 elongated splats at every orientation, which is what the row-span test (xc(dy) +- hw(dy), leftmost / rightmost rows) has
@@ -20,11 +20,12 @@ def _both(dev, monkeypatch, model, cam, bg, deg, scale_modifier=1.0):
     from gpu_util import forward_with_state, product_settings
     st = product_settings(cam, bg, deg, dev, scale_modifier=scale_modifier)
     outs = []
-    for off in ("0", "1"):
-        monkeypatch.setenv("GSR_DEBUG_NO_MINIBLOCK_CULL", off)
+    from mvs_gaussian_splatting_amd import _lib, rasterizer
+    for flags in (0, _lib.DEBUG_NO_MINIBLOCK_CULL):
+        monkeypatch.setattr(rasterizer, "_debug_flags_value", flags)
         outs.append(forward_with_state(dev, st, model.get_xyz, model.get_opacity, shs=model.get_features,
                                        scales=model.get_scaling, rotations=model.get_rotation, binning_mode=2, want_stats=True))
-    monkeypatch.delenv("GSR_DEBUG_NO_MINIBLOCK_CULL")
+    monkeypatch.setattr(rasterizer, "_debug_flags_value", 0)
     # the switch is live: without the cull every instance sits in all 16 lists of its tile (mini-blocks that lie outside
     # the image or are saturated walk nothing, hence <=)
     on, off = outs[0]["stats"], outs[1]["stats"]

@@ -513,7 +513,8 @@ def test_rare_branches_forward_and_backward_match_oracle(gpu_device, mode, monke
     from mvs_gaussian_splatting_amd.synthetic import orbit_camera
     from gpu_util import forward_with_state, product_settings
     from oracle import rasterize_ref
-    monkeypatch.setenv("GSR_BINNING", "keys64" if mode else "two_level")
+    from mvs_gaussian_splatting_amd import rasterizer
+    monkeypatch.setattr(rasterizer, "_binning_mode_value", rasterizer._binning_from_name("keys64" if mode else "two_level"))
     model = _stress_model()
     cam = orbit_camera(1, 8, 208, 136, 120.0, 120.0)
     bg = torch.tensor([0.2, 0.4, 0.1])

@@ -1,0 +1,170 @@
+"""The forward without a host round-trip (ABI v11 ``gsr_forward``: caller-side capacity, counts read on the device,
+overflow visible in pinned memory) against the two-call forward it replaces after the first frame
+(``gsr_forward_preprocess`` + ``gsr_forward_render``, i.e. upstream's per-forward ``num_rendered`` read-back,
+``gaussian_renderer/__init__.py:257-265``): images, radii, per-pixel state and every gradient must be BIT-IDENTICAL;
+a capacity that is too small must be reported, never silently rendered; frames whose depths span more than 24 bits
+take the device-predicated fourth sort pass.  Also the fused densification statistics (``GsrGrads.stats_*``) and the
+roctx switch."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import small_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(dev, P=6000, wide_depth=False, seed=0):
+    model, cam, bg, target = small_scene(P=P, sh_degree=2, width=352, height=208, scale=0.03, seed=seed)
+    if wide_depth:
+        g = torch.Generator().manual_seed(11)
+        z = torch.exp(torch.rand(P, generator=g) * (math.log(2.0e6) - math.log(0.25)) + math.log(0.25))
+        s = z / model._xyz[:, 2]
+        model._xyz *= s[:, None]
+        model._scaling += torch.log(s)[:, None]
+    model.to(dev); cam.to(dev)
+    for p in model.parameters():
+        p.requires_grad_(True)
+    return model, cam, bg.to(dev), target.to(dev)
+
+
+def _step(model, cam, bg, target, fused=True, stats=False):
+    from mvs_gaussian_splatting_amd import render, l1_loss
+    from mvs_gaussian_splatting_amd.synthetic import PipelineParams
+    for p in model.parameters():
+        p.grad = None
+    pipe = PipelineParams()
+    pipe.fuse_activations = fused
+    pipe.fuse_densify_stats = stats
+    pkg = render(cam, model, pipe, bg)
+    l1_loss(pkg["render"], target).backward()
+    return pkg, [p.grad.detach().clone() for p in model.parameters()] + [pkg["viewspace_points"].grad.detach().clone()]
+
+
+@pytest.fixture()
+def fresh_state(monkeypatch):
+    """Every test starts without a remembered capacity and leaves none behind."""
+    from mvs_gaussian_splatting_amd import rasterizer
+    rasterizer.synchronize_counts()
+    rasterizer._states.clear()
+    monkeypatch.setattr(rasterizer, "_sync_free_value", True)
+    yield rasterizer
+    try:
+        rasterizer.synchronize_counts()
+    except Exception:
+        pass
+    rasterizer._states.clear()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("wide_depth", [False, True])
+def test_second_frame_runs_without_readback_and_is_bit_identical(gpu_device, fresh_state, fused, wide_depth):
+    rz = fresh_state
+    model, cam, bg, target = _scene(gpu_device, wide_depth=wide_depth)
+    pkg0, g0 = _step(model, cam, bg, target, fused)                 # first frame: two-call path, learns the capacity
+    assert pkg0["render"].grad_fn.frame_pending is None
+    R0, V0 = rz.frame_counts(pkg0["render"])
+    assert R0 > V0 > 1000
+    pkg1, g1 = _step(model, cam, bg, target, fused)                 # second frame: gsr_forward
+    pend = pkg1["render"].grad_fn.frame_pending
+    assert pend is not None and pend.done and pend.capacity >= int(1.5 * R0)
+    assert rz.frame_counts(pkg1["render"]) == (R0, V0)
+    assert torch.equal(pkg0["render"], pkg1["render"]) and torch.equal(pkg0["radii"], pkg1["radii"])
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+    # forward-only frames (no autograd node): checked by synchronize_counts
+    with torch.no_grad():
+        from mvs_gaussian_splatting_amd import render
+        from mvs_gaussian_splatting_amd.synthetic import PipelineParams
+        img = render(cam, model, PipelineParams(), bg)["render"]
+    rz.synchronize_counts()
+    assert torch.equal(img, pkg0["render"].detach())
+    assert rz.last_counts(gpu_device, model._xyz.shape[0], cam.image_width, cam.image_height) == (R0, V0)
+
+
+def test_raw_abi_lists_and_state_are_those_of_the_two_call_path(gpu_device):
+    """gsr_forward at several capacities (exact, generous) leaves the same sorted lists, ranges, final_T and n_contrib
+    as the two-call forward; the top-digit pass is exercised by the wide-depth cloud."""
+    from gpu_util import forward_with_state, product_settings
+    for wide in (False, True):
+        model, cam, bg, _ = small_scene(P=5000, sh_degree=1, width=320, height=176, scale=0.04, seed=3)
+        if wide:
+            z = torch.exp(torch.rand(5000, generator=torch.Generator().manual_seed(2)) * math.log(4.0e6) + math.log(0.3))
+            s = z / model._xyz[:, 2]
+            model._xyz *= s[:, None]
+            model._scaling += torch.log(s)[:, None]
+        st = product_settings(cam, bg, 1, gpu_device)
+        kw = dict(shs=model.get_features, scales=model.get_scaling, rotations=model.get_rotation)
+        for mode in (0, 2):
+            ref = forward_with_state(gpu_device, st, model.get_xyz, model.get_opacity, binning_mode=mode, **kw)
+            for cap in (ref["R"], ref["R"] + 1, 3 * ref["R"]):
+                out = forward_with_state(gpu_device, st, model.get_xyz, model.get_opacity, binning_mode=mode,
+                                         sync_free_capacity=cap, **kw)
+                assert (out["R"], out["V"]) == (ref["R"], ref["V"])
+                assert np.array_equal(out["point_list"], ref["point_list"]) and np.array_equal(out["keys"], ref["keys"])
+                assert np.array_equal(out["ranges"], ref["ranges"])
+                for k in ("color", "final_T", "n_contrib", "radii"):
+                    assert torch.equal(out[k], ref[k]), k
+
+
+def test_overflow_is_reported_not_rendered_silently(gpu_device, fresh_state):
+    rz = fresh_state
+    model, cam, bg, target = _scene(gpu_device)
+    pkg0, _ = _step(model, cam, bg, target)
+    R0, _ = rz.frame_counts(pkg0["render"])
+    key_state = next(iter(rz._states.values()))
+    key_state.capacity = max(1024, R0 // 3)                      # far too small for the next frame
+    from mvs_gaussian_splatting_amd import _lib, render, l1_loss
+    from mvs_gaussian_splatting_amd.synthetic import PipelineParams
+    pkg = render(cam, model, PipelineParams(), bg)               # issued without a read-back: overflows on the device
+    loss = l1_loss(pkg["render"], target)
+    with pytest.raises(_lib.GsrError, match="overflowed its binning capacity"):
+        loss.backward()                                          # the frame's own backward refuses to run
+    with pytest.raises(_lib.GsrError, match="overflowed"):
+        rz.frame_counts(pkg["render"])
+    assert key_state.capacity >= int(1.5 * R0)                   # ... and the capacity has grown for the frames after it
+    pkg2, g2 = _step(model, cam, bg, target)                     # which are complete again
+    assert torch.equal(pkg2["render"], pkg0["render"])
+    # a forward-only frame that overflowed is reported by the next call into the operator / by synchronize_counts
+    key_state.capacity = max(1024, R0 // 3)
+    with torch.no_grad():
+        render(cam, model, PipelineParams(), bg)
+    with pytest.raises(_lib.GsrError, match="overflowed"):
+        rz.synchronize_counts()
+    rz.synchronize_counts()                                      # reported once per drain; nothing left pending
+
+
+def test_fused_densification_statistics_equal_the_stand_alone_kernel(gpu_device, fresh_state):
+    from mvs_gaussian_splatting_amd import add_densification_stats
+    for fused_inputs in (True, False):
+        model, cam, bg, target = _scene(gpu_device, P=4000, seed=5)
+        _, cam2, _, _ = small_scene(P=4000, sh_degree=2, width=352, height=208, scale=0.03, view=2)
+        cam2.to(gpu_device)
+        g = torch.Generator().manual_seed(3)
+        base = (torch.rand(4000, 1, generator=g).to(gpu_device), torch.randint(0, 5, (4000, 1), generator=g).float().to(gpu_device),
+                torch.randint(0, 6, (4000,), generator=g).float().to(gpu_device))
+        results = []
+        for stats_in_backward in (False, True):
+            model.xyz_gradient_accum, model.denom, model.max_radii2D = (t.clone() for t in base)
+            for c in (cam, cam2):
+                pkg, _ = _step(model, c, bg, target, fused=fused_inputs, stats=stats_in_backward)
+                assert bool(getattr(pkg["viewspace_points"], "_gsr_stats_fused", False)) == stats_in_backward
+                add_densification_stats(model, pkg["viewspace_points"], pkg["radii"])     # no-op for a fused frame
+            results.append((model.xyz_gradient_accum.clone(), model.denom.clone(), model.max_radii2D.clone()))
+        for a, b in zip(*results):
+            assert torch.equal(a, b)
+        assert float(results[0][1].max()) >= base[1].max() + 1
+
+
+def test_markers_switch(gpu_device, fresh_state):
+    from mvs_gaussian_splatting_amd import _lib
+    _lib.enable_markers(True)        # librocprofiler-sdk-roctx.so ships with the ROCm image
+    try:
+        model, cam, bg, target = _scene(gpu_device, P=2000)
+        pkg, _ = _step(model, cam, bg, target)
+        assert torch.isfinite(pkg["render"]).all()
+    finally:
+        _lib.enable_markers(False)

@@ -3,6 +3,7 @@ multi-GPU bench renders.  python tools/bench_views.py"""
 import time
 import torch
 from mvs_gaussian_splatting_amd import render, l1_loss
+from mvs_gaussian_splatting_amd.rasterizer import frame_counts
 from mvs_gaussian_splatting_amd.synthetic import CONFIGS, make_scene, PipelineParams
 
 dev = torch.device("cuda:0")
@@ -40,4 +41,4 @@ for v in range(8):
         step()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    print(f"view {v}: visible {int((pkg['radii'] > 0).sum()):>8}  R {pkg['render'].grad_fn.num_rendered:>9}  fwd {(t1 - t0) * 100:.3f} ms  train {(t2 - t1) * 100:.3f} ms", flush=True)
+    print(f"view {v}: visible {int((pkg['radii'] > 0).sum()):>8}  R {frame_counts(pkg['render'])[0]:>9}  fwd {(t1 - t0) * 100:.3f} ms  train {(t2 - t1) * 100:.3f} ms", flush=True)

@@ -41,3 +41,17 @@ res = prof.collect()
 s.params.profile = None
 s.params.forward_only = 0
 print(f"forward-only: fwd={tf / iters:.3f} ms  " + "  ".join(f"{k}={ms / n:.4f}" for k, (ms, n) in res.items() if n))
+# the forward without the count read-back (gsr_forward, capacity = 1.5 x the instance count): what every frame after the
+# first runs through the operator
+s.forward()
+s.forward_sync_free()
+torch.cuda.synchronize()
+tf = 0.0
+wall0 = __import__("time").perf_counter()
+t0.record()
+for _ in range(iters):
+    s.forward_sync_free()
+t1.record()
+torch.cuda.synchronize()
+wall = (__import__("time").perf_counter() - wall0) * 1e3 / iters
+print(f"sync-free forward: {t0.elapsed_time(t1) / iters:.3f} ms per frame on the device, {wall:.3f} ms wall (back to back, capacity {s.cap})")
