@@ -29,7 +29,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 T
 
 
 def algorithmic_bytes(P, M, R, W, H, passes):
-    """SURVEY.md §8(d) model v1, bytes per launch of each stage."""
+    """SURVEY.md §8(d) model v1, bytes per launch of each stage (every Gaussian priced as if it were visible)."""
     T = ((W + 15) // 16) * ((H + 15) // 16)
     return {
         "preprocess_fwd": P * (44 + 12 * M + 75),
@@ -40,6 +40,20 @@ def algorithmic_bytes(P, M, R, W, H, passes):
         "render_fwd": 40 * R + 20 * W * H,
         "render_bwd": 40 * R + 80 * R + 20 * W * H,
         "preprocess_bwd": P * (175 + 24 * M),
+    }
+
+
+def bytes_really_moved(P, M, V, R, W, H):
+    """Model v2 for the two per-Gaussian stages: the bytes the kernels have to move for THIS frame.
+    A Gaussian outside the frustum costs its 44 bytes of position / scale / rotation / opacity and nothing else: its
+    12 M-byte SH row is never read and its 75 bytes of per-Gaussian state are never written (V = visible Gaussians, a
+    lower bound of the rows read: an on-screen centre whose footprint rounds to zero tiles has its row read too).
+    Backward: every Gaussian gets its gradient rows written (56 + 12 M bytes: the operator returns dense tensors) and
+    its radius read; a visible one also reads its record, slot, position / scale / rotation, SH row (for d rgb / d dir)
+    and its 49-byte instance rows."""
+    return {
+        "preprocess_fwd": 44 * P + (12 * M + 75) * V,
+        "preprocess_bwd": (56 + 12 * M + 4) * P + (64 + 4 + 40 + 12 * M) * V + 49 * R,
     }
 
 
@@ -182,39 +196,31 @@ def main():
     torch.cuda.set_device(dev)
     backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
     backend_note = backend
-    cpu_collectives = backend != "nccl"      # gloo: the 16-byte collectives go through host tensors
-    rccl_ranks = None                        # communicator size proven by an all-reduce of ones over RCCL
-    rccl_failed = False
+    from mvs_gaussian_splatting_amd.dist import negotiate_collectives
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            # one group, two backends: RCCL for device tensors, gloo for host tensors.  RCCL communicators are created at
-            # the first collective: probe now.  The outcome is AGREED over the gloo half (MIN of the per-rank flags), so
-            # that every rank issues the same collectives afterwards; a run that had to fall back to gloo still reports
-            # its timings as diagnostics but is marked invalid (it did not measure the RCCL-over-xGMI all-reduce).
-            dist.init_process_group(backend="cpu:gloo,cuda:nccl")
-            ok, why = 1, ""
-            try:
-                probe = torch.ones(1, device=dev)
-                dist.all_reduce(probe)
-                torch.cuda.synchronize(dev)
-                ok = int(round(float(probe.item()))) == world
-                if not ok:
-                    why = f"all-reduce of ones returned {float(probe.item())}, expected {world}"
-            except Exception as ex:  # noqa: BLE001
-                ok, why = 0, str(ex)[:300]
-            flag = torch.tensor([int(ok)], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # host tensor -> gloo
-            if int(flag.item()) == 1:
-                rccl_ranks = world
-            else:
-                rccl_failed = True
-                cpu_collectives = True
-                backend_note = "gloo (nccl failed to initialise on at least one rank)"
-                print(f"[bench] rank {rank}: RCCL unavailable on this or another rank ({why!r}); every rank switches to "
-                      "gloo for the 16-byte loss all-reduce and the line is marked invalid", file=sys.stderr, flush=True)
-        else:
-            dist.init_process_group(backend=backend)
+        # one group, two backends: RCCL for device tensors, gloo for host tensors
+        dist.init_process_group(backend="cpu:gloo,cuda:nccl" if backend == "nccl" else backend)
+
+    def _probe():
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)
+        torch.cuda.synchronize(dev)
+        return float(probe.item())
+
+    def _agree(flag):
+        t = torch.tensor([flag], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)          # host tensor -> gloo
+        return int(t.item())
+
+    # the probe / agree / fall-back protocol lives in mvs_gaussian_splatting_amd/dist.py (unit-tested with a fake
+    # process group): a run that had to fall back to gloo still reports its timings as diagnostics but is marked invalid
+    plan = negotiate_collectives(world, backend, _probe, _agree)
+    cpu_collectives, rccl_ranks, rccl_failed, backend_note = (plan.cpu_collectives, plan.rccl_ranks, plan.rccl_failed,
+                                                              plan.backend_note)
+    if rccl_failed:
+        print(f"[bench] rank {rank}: RCCL unavailable on this or another rank ({plan.why!r}); every rank switches to "
+              "gloo for the 16-byte loss all-reduce and the line is marked invalid", file=sys.stderr, flush=True)
 
     def all_reduce(t, op):
         if cpu_collectives:
@@ -235,6 +241,9 @@ def main():
         p.requires_grad_(True)
     pipe = PipelineParams()
     pipe.fuse_activations = not args.unfused
+    # the densification statistics are taken inside the backward (GsrGrads.stats_*); the add_densification_stats call of
+    # the reference's loop stays where it is and recognises the frame (--unfused: stand-alone kernel, as the reference)
+    pipe.fuse_densify_stats = not args.unfused
     W, H = cfg.width, cfg.height
     M = (cfg.sh_degree + 1) ** 2
 
@@ -320,9 +329,13 @@ def main():
     # The literal drop-in (INTEGRATION.md option A: the reference's own render() feeding the operator through the
     # getters of scene/gaussian_model.py:151-183 -- torch cat / exp / normalize / sigmoid and their autograd) next to
     # the fused raw-parameter path the headline numbers use; a shorter timed region of the same protocol.
+    from mvs_gaussian_splatting_amd import rasterizer as _rz
+    sync_free = _rz._sync_free_value
+    _rz.synchronize_counts()
     unfused = None
     if pipe.fuse_activations and world == 1:
         pipe.fuse_activations = False
+        pipe.fuse_densify_stats = False
         k2 = max(3, K // 4)
         for _ in range(2):
             fwd_step(); train_step()
@@ -331,6 +344,7 @@ def main():
         unfused = {"unfused_fwd_ms": round(t_uf / k2 * 1e3, 3), "unfused_train_ms": round(t_ut / k2 * 1e3, 3),
                    "unfused_steps": k2}
         pipe.fuse_activations = True
+        pipe.fuse_densify_stats = True
 
     # instances of this rank's view: read back from the stage the operator itself ran
     from mvs_gaussian_splatting_amd.rasterizer import frame_counts
@@ -340,7 +354,10 @@ def main():
         tiles = ((W + 15) // 16) * ((H + 15) // 16)
         tb = max(1, (tiles - 1).bit_length())
         passes = (32 + tb + 7) // 8
-        alg = algorithmic_bytes(P, M, R, W, H, passes)
+        alg_v1 = algorithmic_bytes(P, M, R, W, H, passes)
+        moved = bytes_really_moved(P, M, visible, R, W, H)
+        # what `achieved` / `frac` are priced on: model v2 where it exists, model v1 elsewhere; v1 is printed beside it
+        alg = dict(alg_v1, **moved)
         by_kernel = {}
         for src, n_steps in ((stages_fwd, K), (stages_train, K)):
             for name, (ms, cnt) in src.items():
@@ -358,18 +375,26 @@ def main():
             gbs = alg[name] / (avg_ms * 1e-3) / 1e9
             table[name] = {"avg_ms": round(avg_ms, 4), "launches": cnt, "frames": frames, "algorithmic_bytes": alg[name],
                            "achieved_GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+            if name in moved:
+                g1 = alg_v1[name] / (avg_ms * 1e-3) / 1e9
+                table[name].update({"byte_model": "v2: bytes this frame has to move (culled Gaussians cost 44 B)",
+                                    "algorithmic_bytes_model_v1": alg_v1[name], "achieved_GBs_model_v1": round(g1, 1),
+                                    "frac_of_hbm_peak_model_v1": round(g1 / HBM_PEAK_GBS, 4)})
             if name == "radix_sort":
                 # SURVEY's model v1 prices upstream's 64-bit (tile, depth) sort of R pairs (152 R).  The default binning
                 # does not run that sort: it compacts the V visible Gaussians (16 P read, 8 V written), sorts them by
                 # 24-bit depth keys (3 passes x (4 V histogram read + 8 V read + 8 V written)) and partitions the R
                 # instances by tile id (2 passes x (4 R + 8 R + 8 R)).  Priced on the bytes it really moves:
-                moved = 16 * P + 8 * visible + 3 * 20 * visible + 2 * 20 * R
-                table[name]["bytes_moved_two_level"] = moved
-                table[name]["achieved_GBs_two_level"] = round(moved / (avg_ms * 1e-3) / 1e9, 1)
-                table[name]["frac_of_hbm_peak_two_level"] = round(moved / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                mv = 16 * P + 8 * visible + 3 * 20 * visible + 2 * 20 * R
+                table[name]["bytes_moved_two_level"] = mv
+                table[name]["achieved_GBs_two_level"] = round(mv / (avg_ms * 1e-3) / 1e9, 1)
+                table[name]["frac_of_hbm_peak_two_level"] = round(mv / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         fwd_names = ["preprocess_fwd", "scan_block_sums", "duplicate_with_keys", "radix_sort", "identify_tile_ranges",
                      "render_fwd"]
+        # `roofline`: the longest kernel of the metric's first half (the forward); `roofline_step`: the longest kernel of
+        # its second half (the train step) -- named explicitly, so that the headline cannot drift to a flattering kernel
         dominant = max((n for n in table), key=lambda n: table[n]["avg_ms"] * (1 if n in fwd_names else 0))
+        dominant_step = max((n for n in table), key=lambda n: table[n]["avg_ms"])
         # HBM bytes and instruction counts per launch come from SEPARATE rocprofv3 --pmc passes of this same command
         # (tools/capture_profiles.sh + tools/refresh_profiles.py -> profiles/traffic.json).  The file carries the stamp
         # of the kernel sources it was measured on: on a mismatch the fields are nulled rather than quoted stale.
@@ -415,11 +440,24 @@ def main():
                          "note": "utilisations are lower bounds of a unit's busy share at the 2.4 GHz peak clock (the chip "
                                  "clocks at 1.9-2.3 GHz under VALU load; half- and quarter-rate instructions occupy the "
                                  "VALU for 2-3.5x the floor) and cannot exceed 1"}
-            return {"kernel": kernel, "bound": "hbm", "achieved": table[kernel]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": table[kernel]["frac_of_hbm_peak"], "traffic": entry.get("hbm_bytes_per_launch"),
-                    "avg_launch_ms": table[kernel]["avg_ms"], "algorithmic_bytes_per_launch": alg[kernel],
-                    "issue": issue, "pmc_source": pmc_note}
+            out = {"kernel": kernel, "bound": "hbm", "achieved": table[kernel]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                   "unit": "GB/s", "frac": table[kernel]["frac_of_hbm_peak"], "traffic": entry.get("hbm_bytes_per_launch"),
+                   "avg_launch_ms": table[kernel]["avg_ms"], "algorithmic_bytes_per_launch": alg[kernel],
+                   "issue": issue, "pmc_source": pmc_note}
+            if kernel in moved:
+                out.update({"byte_model": table[kernel]["byte_model"],
+                            "achieved_model_v1": table[kernel]["achieved_GBs_model_v1"],
+                            "frac_model_v1": table[kernel]["frac_of_hbm_peak_model_v1"],
+                            "algorithmic_bytes_per_launch_model_v1": alg_v1[kernel]})
+            # no kernel moves bytes faster than the device can copy them: an `achieved` far above the measured copy rate
+            # means the byte model counts bytes the kernel never touches
+            out["sane"] = bool(out["achieved"] <= 1.3 * copy_GBs)
+            if not out["sane"]:
+                print(f"[bench] roofline of {kernel}: achieved {out['achieved']} GB/s exceeds 1.3 x the measured copy rate "
+                      f"{copy_GBs} GB/s -- the byte model over-counts", file=sys.stderr, flush=True)
+            return out
 
+        copy_GBs = round(copy_ceiling(), 1)
         roof = roofline_of(dominant)
         fwd_ms = t_fwd / K * 1e3
         train_ms = t_train / K * 1e3
@@ -432,13 +470,17 @@ def main():
             "fwd_fps": round(1e3 / fwd_ms, 2),
             "fwd_step_ms_p10_p50_p90": [pct(fwd_steps, 0.1), pct(fwd_steps, 0.5), pct(fwd_steps, 0.9)],
             "train_step_ms_p10_p50_p90": [pct(train_steps, 0.1), pct(train_steps, 0.5), pct(train_steps, 0.9)],
-            "hbm_copy_measured_GBs": round(copy_ceiling(), 1),
+            "hbm_copy_measured_GBs": copy_GBs,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {P} Gaussians, SH degree {cfg.sh_degree}, {W}x{H}, one view per GPU; "
                                    "value = forward-only steps, ms_per_step = render+L1+backward+densify-stats steps",
                        "gaussians": P, "visible": visible, "instances_R": R, "views_per_step": world,
-                       "inputs": ("raw parameters (split SH, exp/normalize/sigmoid inside the kernels)"
+                       "inputs": ("raw parameters (split SH, exp/normalize/sigmoid inside the kernels; INTEGRATION.md "
+                                  "option B -- the literal drop-in through the reference getters is unfused_*_ms)"
                                   if pipe.fuse_activations else "reference getters (torch cat/exp/normalize/sigmoid)"),
+                       "host_sync": ("first frame reads num_rendered back, later frames run gsr_forward with a capacity "
+                                     "(no read-back)" if sync_free else "num_rendered read back in every frame"),
+                       "densify_stats": "fused into preprocess_bwd" if pipe.fuse_densify_stats else "stand-alone kernel",
                        "collective_backend": backend_note if world > 1 else None,
                        "rccl_ranks": rccl_ranks,
                        # invalid: a reduced problem, or ranks on distinct devices whose RCCL communicator did not come
@@ -446,6 +488,7 @@ def main():
                        # ... and a rehearsal with several ranks on ONE card (GSR_BENCH_SHARE_GPU=1) is never a multi-GPU result
                        "valid": args.gaussians is None and not rccl_failed and not (share and world > 1)},
             "roofline": roof,
+            "roofline_step": roofline_of(dominant_step),
             # the two compositing kernels north_star singles out (VALU-issue-bound: DESIGN.md section 5)
             "roofline_render_fwd": roofline_of("render_fwd") if "render_fwd" in table else None,
             "roofline_render_bwd": roofline_of("render_bwd") if "render_bwd" in table else None,

@@ -406,7 +406,11 @@ __device__ inline float dpp_add(float v) {
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int SB_DUMMY = WAVE;                 // LDS slot of the all-zero record the lists are padded with
 constexpr int SB_LIST = WAVE + 8;              // list capacity (entries past the longest list are read, never used)
-constexpr int SB_SLAB = 5 * 2 * WAVE;          // doubles: 65 x 9 = 585 used, a multiple of 64 x 16 bytes for the zero-fill
+#ifndef GSR_FOLD
+#define GSR_FOLD 2        // 0: DPP fold (builtins), 1: DPP fold with bank-masked adds (inline asm), 2: transposition through LDS
+#endif
+constexpr int SB_SLAB = 586;                   // doubles: 65 x 9 = 585 used; 4688 bytes = 4 x 1024 + 37 x 16 for the zero-fill
+constexpr int XCH_ROW = WAVE + 4;              // floats per row of the exchange buffer: rows 16 bytes apart in the banks
 struct SbLds {
   float4 A[WAVE + 1];
   float4 B[WAVE + 1];
@@ -416,6 +420,11 @@ struct SbLds {
   // instance depends on what else is in the round, and a float sum would make the last bit of a gradient depend on the
   // binning mode (a double sum of four floats is exact unless their exponents span more than 2^29).
   double slab[SB_SLAB];
+#if GSR_FOLD == 2
+  // the nine per-lane partial sums of a list step, [value][lane]: written by every lane, read back transposed (lane q of
+  // a row reads the 16 partials of value q of its row) -- 13 LDS instructions instead of 26 half-rate DPP operations
+  float xch[9][XCH_ROW];
+#endif
 };
 
 // lanes of the banks in BANK_MASK (bank = 4 consecutive lanes of a 16-lane row) take b, the others keep a
@@ -441,6 +450,43 @@ __device__ __forceinline__ void row_fold9(const float (&v)[9], float& n0, float&
   n2 = m4;
   n0 = dpp_add<0xB1>(n0); n1 = dpp_add<0xB1>(n1); n2 = dpp_add<0xB1>(n2);      // quad_perm [1,0,3,2]
   n0 = dpp_add<0x4E>(n0); n1 = dpp_add<0x4E>(n1); n2 = dpp_add<0x4E>(n2);      // quad_perm [2,3,0,1]
+}
+
+// The same sums with bank-masked DPP adds (v_add_f32_dpp leaves the lanes outside bank_mask untouched, which merges two
+// values into one register without a separate v_mov_dpp): 9 + 5 + 6 = 20 operations instead of 26.  Same result layout as
+// row_fold9.  The operands are folded in place (v is clobbered).  A DPP operand must not have been written by one of
+// the two previous instructions: the order below keeps every producer at least two instructions ahead of its reader,
+// the s_nop covers whatever the compiler placed in front of the block.
+__device__ __forceinline__ void row_fold9_masked(float (&v)[9], float& n0, float& n1, float& n2) {
+  asm volatile(
+      "s_nop 1\n\t"
+      // stage 1: lanes l and l+8.  Odd registers keep their own sum in lanes 8-15 and take the even one's in lanes 0-7
+      "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %3, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %5, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %7, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      // stage 2: lanes i and 7-i of each half row.  %3 / %7 keep their own sums in banks 1, 3 and take %1 / %5 in banks 0, 2
+      "v_add_f32_dpp %8, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %7, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %3, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %7, %5, %5 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+      // stage 3: the four lanes of every bank
+      "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %7, %7, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]));
+  n0 = v[3];
+  n1 = v[7];
+  n2 = v[8];
 }
 
 __device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, int W, int H, int grid_x,
@@ -549,7 +595,8 @@ __device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, i
     {   // zero the slab, pad the lists
       float4* z = reinterpret_cast<float4*>(L.slab);
 #pragma unroll
-      for (int t = 0; t < SB_SLAB * 8 / (16 * WAVE); ++t) z[t * WAVE + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int t = 0; t < 4; ++t) z[t * WAVE + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lane < (SB_SLAB * 8 - 4 * WAVE * 16) / 16) z[4 * WAVE + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
       const uint32_t dd = 16u * SB_DUMMY * 0x10001u;
       uint4* l4 = reinterpret_cast<uint4*>(&L.list[0][0]);
       if (lane < 4 * SB_LIST * 2 / 16) l4[lane] = make_uint4(dd, dd, dd, dd);
@@ -631,8 +678,39 @@ __device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, i
           v[3] = fmaf(dx0, v[1], fmaf(-dy0, Sx, Sxy));
           v[5] = S;
         }
+#if GSR_FOLD == 2
+        // transpose through LDS: every lane stores its nine partial sums, lane j < 9 of a row reads the 16 partials of
+        // value j of its row and adds them in a fixed tree -- then holds the row's sum of value j and adds it to the slab
+        {
+          float* xw = &L.xch[0][lane];
+#pragma unroll
+          for (int t = 0; t < 9; ++t) xw[t * XCH_ROW] = v[t];
+        }
+        __builtin_amdgcn_wave_barrier();      // LDS operations of one wave execute in order
+        if (q < 9) {
+          const float4* xr = reinterpret_cast<const float4*>(&L.xch[q][16 * grp]);
+          const float4 x0 = xr[0], x1 = xr[1], x2 = xr[2], x3 = xr[3];
+          const float nn = (((x0.x + x0.y) + (x0.z + x0.w)) + ((x1.x + x1.y) + (x1.z + x1.w))) +
+                           (((x2.x + x2.y) + (x2.z + x2.w)) + ((x3.x + x3.y) + (x3.z + x3.w)));
+          double* dst = L.slab + 9 * (e0 >> 4) + q;
+          if (!((clash >> i) & 1ull)) {
+            *dst += (double)nn;
+          } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              if (grp == g) *dst += (double)nn;
+              __builtin_amdgcn_wave_barrier();
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();      // the next step's stores follow this step's loads
+#else
         float n0, n1, n2;
+#if GSR_FOLD == 1
+        row_fold9_masked(v, n0, n1, n2);
+#else
         row_fold9(v, n0, n1, n2);
+#endif
         // lane j of bank k takes the bank's value of n0 (j = 0), n1 (j = 1), n2 (j = 2, bank 0 only): the nine sums of the
         // row sit in nine lanes and go to the slab with one read-add-write (LDS float atomics retire about one lane per
         // cycle per CU: far slower)
@@ -648,6 +726,7 @@ __device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, i
             __builtin_amdgcn_wave_barrier();     // LDS operations of one wave execute in order
           }
         }
+#endif
         e0 = e1;
       }
     };

@@ -36,6 +36,45 @@ def init_process_group(backend: Optional[str] = None, device: Optional[torch.dev
     dist.init_process_group(backend=backend, **kw)
 
 
+class CollectivePlan:
+    """Outcome of :func:`negotiate_collectives`, identical on every rank."""
+    __slots__ = ("cpu_collectives", "rccl_ranks", "rccl_failed", "backend_note", "why")
+
+    def __init__(self, cpu_collectives, rccl_ranks, rccl_failed, backend_note, why=""):
+        self.cpu_collectives, self.rccl_ranks, self.rccl_failed = cpu_collectives, rccl_ranks, rccl_failed
+        self.backend_note, self.why = backend_note, why
+
+
+def negotiate_collectives(world: int, backend: str, probe_device_allreduce: Callable[[], float],
+                          agree_min: Callable[[int], int]) -> CollectivePlan:
+    """Decide -- THE SAME WAY ON EVERY RANK -- whether the path's one collective (the 16-byte loss all-reduce) runs on
+    device tensors over RCCL or has to fall back to host tensors over gloo.
+
+    RCCL communicators are created lazily, at the first collective, and may come up on some ranks and fail on others
+    (a missing peer device, a duplicate device in a one-card rehearsal).  If each rank acted on its own outcome the
+    ranks would issue different collectives afterwards and hang.  So: every rank probes with an all-reduce of ones
+    (``probe_device_allreduce`` returns the reduced value or raises), turns the outcome into a 0/1 flag, and the flags
+    are reduced with MIN over a channel that is known to work (``agree_min``: the gloo half of the process group).
+    Only a unanimous 1 keeps RCCL.  Pure function of its two callables: unit-tested with fakes
+    (tests/test_bench_protocol.py)."""
+    if world <= 1:
+        return CollectivePlan(False, None, False, backend)
+    if backend != "nccl":
+        return CollectivePlan(True, None, False, backend)
+    ok, why = 1, ""
+    try:
+        got = float(probe_device_allreduce())
+        if int(round(got)) != world:
+            ok, why = 0, f"all-reduce of ones returned {got}, expected {world}"
+    except Exception as ex:  # noqa: BLE001 -- any failure of the probe means "no RCCL on this rank"
+        ok, why = 0, str(ex)[:300]
+    agreed = int(agree_min(int(ok)))          # every rank reaches this line, whatever its own outcome
+    if agreed == 1:
+        return CollectivePlan(False, world, False, "nccl", "")
+    return CollectivePlan(True, None, True, "gloo (nccl failed to initialise on at least one rank)",
+                          why or "another rank reported a failed probe")
+
+
 def sharded_train_step(model, cameras: Sequence, targets: Sequence[torch.Tensor], bg: torch.Tensor, pipe,
                        render_fn: Optional[Callable] = None, loss_fn: Optional[Callable] = None,
                        stats_fn: Optional[Callable] = None, group=None) -> dict:

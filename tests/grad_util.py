@@ -13,13 +13,22 @@ so that what remains is differentiable-identical on both sides and held to 1e-5.
 The error measure is per parameter tensor, max-norm relative:  max|got - ref| / max|ref|  (not per element: elements
 whose gradient is 1e-6 of the tensor's largest are compared to the same absolute bar).  The only escape is
 conditioning: where an independent float32 implementation (the oracle itself in float32, same weights) misses 1e-5
-against float64, the bar becomes 2 x that implementation's error.  Both numbers are printed for every tensor.
+against float64, the bar becomes 2 x that implementation's error -- and never more than ESCAPE_CAP (2e-4): a scene so
+badly conditioned that float32 itself is further off fails instead of silently opening the bar.  Both numbers are
+printed for every tensor.  (Worst bars seen on the round-2 suite: means2D 2.9e-5, xyz 1.1e-4.)
+
+The masked pixels are not left unchecked: compare_grads_unmasked() runs the same scene with EVERY pixel in the loss
+(plain L1) against float64 at the loose bar of round 1 (2e-3 max-norm relative) and requires finite gradients -- a
+forward / backward decision mismatch on a threshold pixel (different clamp scope, a sub-block cut-off, a recomputed
+T / (1 - alpha)) shows up there as an error of the order of the pixel's whole contribution.
 """
 import torch
 
 MARGIN = 1e-4
 SIGN_EPS = 1e-5
 TOL = 1e-5
+ESCAPE_CAP = 2e-4       # the conditioning escape (2 x the float32 oracle's own error) never opens the bar beyond this
+UNMASKED_TOL = 2e-3     # every pixel in the loss, threshold-fragile ones included
 
 RAW = ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")
 
@@ -92,9 +101,32 @@ def compare_grads(got, ref, ref32=None, label=""):
         e = float((g - r).abs().max()) / scale
         e32 = float((ref32[k].double() - r).abs().max()) / scale if ref32 is not None else 0.0
         tol = max(TOL, 2.0 * e32)
+        assert tol <= ESCAPE_CAP, (f"{label}: {k} is too ill-conditioned to test (the float32 oracle itself is {e32:.2e} "
+                                   f"off float64): the scene must be made better conditioned, not the bar wider")
         rows.append(f"{k}: err {e:.2e} (float32 oracle {e32:.2e}, bar {tol:.2e})")
         if e > tol:
             bad[k] = (e, e32, tol)
     print(f"[grad parity] {label}: " + "; ".join(rows))
     assert not bad, f"{label}: max-norm relative gradient error above the bar: {bad}"
     return rows
+
+
+def compare_grads_unmasked(got, ref, n_fragile, label=""):
+    """Every pixel in the loss (weights all one): finite, and within UNMASKED_TOL of float64 per tensor (max-norm
+    relative).  Prints the count of threshold-fragile pixels the masked comparison leaves out."""
+    rows, bad = [], {}
+    for k, r in ref.items():
+        if r.numel() == 0:
+            continue
+        r = r.double()
+        g = got[k].double().cpu()
+        assert torch.isfinite(g).all(), f"{label}: non-finite gradient in {k} (unmasked loss)"
+        scale = float(r.abs().max())
+        if scale == 0.0:
+            continue
+        e = float((g - r).abs().max()) / scale
+        rows.append(f"{k}: {e:.2e}")
+        if e > UNMASKED_TOL:
+            bad[k] = e
+    print(f"[grad parity, unmasked, {n_fragile} fragile pixels in the loss] {label}: " + "; ".join(rows))
+    assert not bad, f"{label}: unmasked gradient error above {UNMASKED_TOL}: {bad}"

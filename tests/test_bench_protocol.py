@@ -1,0 +1,92 @@
+"""bench.py's probe / agree / fall-back protocol for the path's only collective (mvs_gaussian_splatting_amd/dist.py:
+negotiate_collectives) on a FAKE process group: N threads stand for N ranks, the agreement channel is a barrier-based
+MIN all-reduce with a timeout -- a rank that skips the agreement (or enters it twice) makes the test fail instead of
+hanging the first real 8-GPU run.  No GPU, no torch.distributed."""
+import threading
+
+import pytest
+
+from mvs_gaussian_splatting_amd.dist import negotiate_collectives
+
+
+class FakeGroup:
+    """MIN all-reduce over `world` threads; every call must be matched by every rank (else BrokenBarrierError)."""
+
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world, timeout=20)
+        self.values = [None] * world
+        self.calls = [0] * world
+
+    def agree_min(self, rank, flag):
+        self.calls[rank] += 1
+        self.values[rank] = flag
+        self.barrier.wait()
+        out = min(self.values)
+        self.barrier.wait()          # nobody overwrites `values` before everybody has read them
+        return out
+
+
+def _run(world, probe_of_rank, backend="nccl"):
+    grp = FakeGroup(world)
+    plans, errors = [None] * world, []
+
+    def rank_main(r):
+        try:
+            plans[r] = negotiate_collectives(world, backend, lambda: probe_of_rank(r), lambda f: grp.agree_min(r, f))
+        except Exception as ex:  # noqa: BLE001
+            errors.append((r, repr(ex)))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=30)
+        assert not t.is_alive(), "a rank hung in the negotiation"
+    assert not errors, errors
+    return plans, grp
+
+
+def _same(plans):
+    key = lambda p: (p.cpu_collectives, p.rccl_ranks, p.rccl_failed, p.backend_note)  # noqa: E731
+    assert len({key(p) for p in plans}) == 1, [key(p) for p in plans]
+    return plans[0]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_all_ranks_up_keeps_rccl(world):
+    plans, grp = _run(world, lambda r: float(world))
+    p = _same(plans)
+    assert not p.cpu_collectives and p.rccl_ranks == world and not p.rccl_failed and p.backend_note == "nccl"
+    assert grp.calls == [1] * world
+
+
+@pytest.mark.parametrize("world,bad", [(2, {1}), (8, {3}), (8, {0, 7}), (4, {0, 1, 2, 3})])
+def test_a_failed_probe_on_any_rank_switches_every_rank(world, bad):
+    def probe(r):
+        if r in bad:
+            raise RuntimeError("NCCL error: duplicate GPU detected")
+        return float(world)
+    plans, grp = _run(world, probe)
+    p = _same(plans)
+    assert p.cpu_collectives and p.rccl_failed and p.rccl_ranks is None and p.backend_note.startswith("gloo")
+    assert grp.calls == [1] * world                      # the healthy ranks took part in the agreement too
+    for r in range(world):                               # ... and each rank can say why
+        assert ("duplicate GPU" in plans[r].why) == (r in bad)
+
+
+def test_a_short_communicator_is_a_failed_probe():
+    """An all-reduce of ones that returns less than the world size means RCCL formed a smaller communicator."""
+    plans, _ = _run(4, lambda r: 2.0 if r < 2 else 4.0)
+    p = _same(plans)
+    assert p.rccl_failed and p.cpu_collectives
+    assert "returned 2.0, expected 4" in plans[0].why
+
+
+def test_single_process_and_explicit_gloo_need_no_agreement():
+    def boom(*a):
+        raise AssertionError("must not be called")
+    p = negotiate_collectives(1, "nccl", boom, boom)
+    assert not p.cpu_collectives and not p.rccl_failed and p.rccl_ranks is None
+    p = negotiate_collectives(4, "gloo", boom, boom)
+    assert p.cpu_collectives and not p.rccl_failed and p.backend_note == "gloo"

@@ -130,10 +130,11 @@ def test_empty_and_degenerate_inputs(gpu_device):
     assert int((radii > 0).sum()) > 0 and torch.allclose(col.cpu(), expect)
 
 
-def _masked_grad_parity(dev, model, cam, bg, target, deg, label, use_cov=False, use_colors=None, smod=1.0):
-    """float64 oracle defines the loss weights; float32 oracle bounds the conditioning; HIP must meet the bar."""
+def _masked_grad_parity(dev, model, cam, bg, target, deg, label, use_cov=False, use_colors=None, smod=1.0, unmasked=True):
+    """float64 oracle defines the loss weights; float32 oracle bounds the conditioning; HIP must meet the bar.
+    unmasked: also run the plain L1 loss over EVERY pixel (the threshold-fragile ones included) at the loose bar."""
     from gpu_util import grads_product, product_settings
-    from grad_util import grads_oracle, compare_grads
+    from grad_util import grads_oracle, compare_grads, compare_grads_unmasked
     st_o = make_settings(cam, bg, deg, scale_modifier=smod)
     ref, weight, aux, col64 = grads_oracle(model, st_o, target, use_cov=use_cov, use_colors=use_colors)
     ref32, _, _, _ = grads_oracle(model, st_o, target, dtype=torch.float32, use_cov=use_cov, use_colors=use_colors,
@@ -150,6 +151,12 @@ def _masked_grad_parity(dev, model, cam, bg, target, deg, label, use_cov=False, 
         if k != "means2D" and r.numel():
             assert float(r.abs().max()) > 0.0, k
     assert float(ref["means2D"][:, :2].abs().max()) > 0.0
+    if unmasked:
+        ones = torch.ones_like(weight)
+        ref_u, _, _, _ = grads_oracle(model, st_o, target, use_cov=use_cov, use_colors=use_colors, weight=ones)
+        got_u, _ = grads_product(dev, model, product_settings(cam, bg, deg, dev, scale_modifier=smod), target, ones,
+                                 use_cov, use_colors)
+        compare_grads_unmasked(got_u, ref_u, n_fragile, label)
     return got, ref, weight, aux
 
 
