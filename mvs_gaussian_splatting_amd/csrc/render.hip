@@ -406,11 +406,7 @@ __device__ inline float dpp_add(float v) {
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int SB_DUMMY = WAVE;                 // LDS slot of the all-zero record the lists are padded with
 constexpr int SB_LIST = WAVE + 8;              // list capacity (entries past the longest list are read, never used)
-#ifndef GSR_FOLD
-#define GSR_FOLD 2        // 0: DPP fold (builtins), 1: DPP fold with bank-masked adds (inline asm), 2: transposition through LDS
-#endif
-constexpr int SB_SLAB = 586;                   // doubles: 65 x 9 = 585 used; 4688 bytes = 4 x 1024 + 37 x 16 for the zero-fill
-constexpr int XCH_ROW = WAVE + 4;              // floats per row of the exchange buffer: rows 16 bytes apart in the banks
+constexpr int SB_SLAB = 5 * 2 * WAVE;          // doubles: 65 x 9 = 585 used, a multiple of 64 x 16 bytes for the zero-fill
 struct SbLds {
   float4 A[WAVE + 1];
   float4 B[WAVE + 1];
@@ -420,43 +416,15 @@ struct SbLds {
   // instance depends on what else is in the round, and a float sum would make the last bit of a gradient depend on the
   // binning mode (a double sum of four floats is exact unless their exponents span more than 2^29).
   double slab[SB_SLAB];
-#if GSR_FOLD == 2
-  // the nine per-lane partial sums of a list step, [value][lane]: written by every lane, read back transposed (lane q of
-  // a row reads the 16 partials of value q of its row) -- 13 LDS instructions instead of 26 half-rate DPP operations
-  float xch[9][XCH_ROW];
-#endif
 };
 
-// lanes of the banks in BANK_MASK (bank = 4 consecutive lanes of a 16-lane row) take b, the others keep a
-template <int BANK_MASK>
-__device__ __forceinline__ float dpp_merge(float a, float b) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(a), __float_as_int(b), 0xE4, 0xf, BANK_MASK, false));
-}
-// Sums of nine values over each 16-lane row.  Result: n0 banks (0,1,2,3) = sums of (v0, v2, v1, v3), n1 banks = sums of
-// (v4, v6, v5, v7), n2 every bank = sum of v8 (each sum in all four lanes of its bank).
-__device__ __forceinline__ void row_fold9(const float (&v)[9], float& n0, float& n1, float& n2) {
-  float w[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) w[i] = dpp_add<0x128>(v[i]);            // row_ror:8  -> lanes l and l+8 agree
-  float m0 = dpp_merge<0xc>(w[0], w[1]);                              // lanes 0-7: v0, lanes 8-15: v1
-  float m1 = dpp_merge<0xc>(w[2], w[3]);
-  float m2 = dpp_merge<0xc>(w[4], w[5]);
-  float m3 = dpp_merge<0xc>(w[6], w[7]);
-  float m4 = w[8];
-  m0 = dpp_add<0x141>(m0); m1 = dpp_add<0x141>(m1); m2 = dpp_add<0x141>(m2);    // row_half_mirror: lanes i and 7-i
-  m3 = dpp_add<0x141>(m3); m4 = dpp_add<0x141>(m4);
-  n0 = dpp_merge<0xa>(m0, m1);                                        // banks 0,2 from m0 (v0 | v1), banks 1,3 from m1
-  n1 = dpp_merge<0xa>(m2, m3);
-  n2 = m4;
-  n0 = dpp_add<0xB1>(n0); n1 = dpp_add<0xB1>(n1); n2 = dpp_add<0xB1>(n2);      // quad_perm [1,0,3,2]
-  n0 = dpp_add<0x4E>(n0); n1 = dpp_add<0x4E>(n1); n2 = dpp_add<0x4E>(n2);      // quad_perm [2,3,0,1]
-}
-
-// The same sums with bank-masked DPP adds (v_add_f32_dpp leaves the lanes outside bank_mask untouched, which merges two
-// values into one register without a separate v_mov_dpp): 9 + 5 + 6 = 20 operations instead of 26.  Same result layout as
-// row_fold9.  The operands are folded in place (v is clobbered).  A DPP operand must not have been written by one of
-// the two previous instructions: the order below keeps every producer at least two instructions ahead of its reader,
-// the s_nop covers whatever the compiler placed in front of the block.
+// Sums of nine values over each 16-lane row with bank-masked DPP adds (v_add_f32_dpp leaves the lanes outside bank_mask
+// untouched, which merges two values into one register without a separate v_mov_dpp): 9 + 5 + 6 = 20 operations -- the
+// builtin form (__builtin_amdgcn_update_dpp + add) needed 26, and a transposition through LDS (13 LDS instructions + 15
+// adds) measured no faster (profiles/r03/ab_fold_c4.txt, ab_fold_c3.txt: fold0 = builtin, fold1 = this, fold2 = LDS).  Result: n0 banks (0,1,2,3) = sums of (v0, v2, v1, v3), n1 banks =
+// sums of (v4, v6, v5, v7), n2 every bank = sum of v8 (each sum in all four lanes of its bank).  v is clobbered.
+// A DPP operand must not have been written by one of the two previous instructions: the order below keeps every
+// producer at least two instructions ahead of its reader, the s_nop covers whatever the compiler placed in front.
 __device__ __forceinline__ void row_fold9_masked(float (&v)[9], float& n0, float& n1, float& n2) {
   asm volatile(
       "s_nop 1\n\t"
@@ -510,9 +478,12 @@ __device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, i
   asm volatile("" : "+v"(pxf0), "+v"(pxf1), "+v"(pyf0), "+v"(pyf1));      // keep them in registers
   const size_t HW = (size_t)W * H;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-  // per pixel: T (running transmittance in front of the current instance), Bk = sum over the
-  // instances behind of (c.dL_dpix)*alpha*T  +  T_final*(bg.dL_dpix)
-  float T[4], Bk[4], dpr[4], dpg[4], dpb[4];
+  // per pixel: T (running transmittance in front of the current instance) and U = (sum over the instances behind of
+  // (c . dL_dpix) alpha T  +  T_final (bg . dL_dpix)) / T -- the colour the pixel shows behind the current instance,
+  // dotted with dL_dpix.  With D = c . dL_dpix - U:  dL_dalpha = T D  and  U <- U + alpha D  (a convex combination: U
+  // never leaves the range of the c . dL_dpix values, and two instructions per pair fewer than carrying the
+  // un-normalised sum, which needs it divided by 1 - alpha)
+  float T[4], U[4], dpr[4], dpg[4], dpb[4];
   uint32_t last[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -524,7 +495,7 @@ __device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, i
     dpr[k] = in ? dL_dpix[pix] : 0.0f;
     dpg[k] = in ? dL_dpix[HW + pix] : 0.0f;
     dpb[k] = in ? dL_dpix[2 * HW + pix] : 0.0f;
-    Bk[k] = T[k] * (bg0 * dpr[k] + bg1 * dpg[k] + bg2 * dpb[k]);
+    U[k] = bg0 * dpr[k] + bg1 * dpg[k] + bg2 * dpb[k];
   }
   const uint2 range = ranges[tile];
   const uint32_t start = range.x;
@@ -573,7 +544,7 @@ __device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, i
   }
 
   while (hi > 0) {
-    const uint32_t cur_lo = lo;
+    const uint32_t cur_lo = lo, hi_r = hi;      // this round: list positions cur_lo + 1 .. hi_r (1-based)
     const bool have = lo + lane < hi;
     // sub-blocks that still have a contributor in this round (1-based indices cur_lo + 1 .. hi)
     const uint32_t active = (sub_last[0] > cur_lo ? 1u : 0u) | (sub_last[1] > cur_lo ? 2u : 0u) |
@@ -595,8 +566,7 @@ __device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, i
     {   // zero the slab, pad the lists
       float4* z = reinterpret_cast<float4*>(L.slab);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) z[t * WAVE + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (lane < (SB_SLAB * 8 - 4 * WAVE * 16) / 16) z[4 * WAVE + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int t = 0; t < SB_SLAB * 8 / (16 * WAVE); ++t) z[t * WAVE + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
       const uint32_t dd = 16u * SB_DUMMY * 0x10001u;
       uint4* l4 = reinterpret_cast<uint4*>(&L.list[0][0]);
       if (lane < 4 * SB_LIST * 2 / 16) l4[lane] = make_uint4(dd, dd, dd, dd);
@@ -629,9 +599,26 @@ __device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, i
       clash = __builtin_amdgcn_ballot_w64((a != dm && (a == b || a == c || a == d)) || (b != dm && (b == c || b == d)) ||
                                           (c != dm && c == d));
     }
-    // two copies of the walk: the 0.99 clamp costs an instruction per pixel and almost no round needs it
-    auto walk = [&](auto clamped_c) {
+    // A pixel takes part from its last contributor on (walking back to front): position <= last[k].  That compare is
+    // needed per pair only in the round in which the pixel's last contributor lies strictly inside; in every other round
+    // the pixel is in for the whole round or out for the whole round, and the per-pixel alpha threshold says which
+    // (1/255, or +inf: the alpha test then fails for every instance and the pixel's state passes through untouched).
+    // TESTED = false is the walk for rounds without such a pixel: one compare per pair instead of two.
+    float thr[4];
+    bool waking = false;
+    uint32_t kmask = 0;       // quad positions with at least one pixel that is in for this round
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool in_all = last[k] >= hi_r, out_all = last[k] <= cur_lo;
+      waking = waking || !(in_all || out_all);
+      thr[k] = in_all ? ALPHA_MIN : __builtin_inff();
+      kmask |= (__builtin_amdgcn_ballot_w64(!out_all) != 0ull) ? (1u << k) : 0u;
+    }
+    const bool tested_round = __builtin_amdgcn_ballot_w64(waking) != 0ull;
+    // copies of the walk: the 0.99 clamp costs an instruction per pixel and almost no round needs it
+    auto walk = [&](auto clamped_c, auto tested_c) {
       constexpr bool CLAMPED = decltype(clamped_c)::value;
+      constexpr bool TESTED = decltype(tested_c)::value;
       uint32_t e0 = mylist[0];
       for (uint32_t i = 0; i < nmax; ++i) {
         const uint32_t e1 = mylist[i + 1];
@@ -646,21 +633,27 @@ __device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, i
         float S = 0.f, Sx = 0.f, Sy = 0.f, Sxy = 0.f;
   #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const bool live = pos1 <= last[k];
-          if (__builtin_amdgcn_ballot_w64(live) == 0ull) continue;      // every pixel of this quad position is past its last contributor
+          bool live = true;
+          if (TESTED) {
+            live = pos1 <= last[k];
+            if (__builtin_amdgcn_ballot_w64(live) == 0ull) continue;    // every pixel of this quad position is past its last contributor
+          } else if (!((kmask >> k) & 1u)) {
+            continue;                                                   // ... for the whole round
+          }
           const float dx = a.x - ((k & 1) ? pxf1 : pxf0), dy = a.y - ((k >> 1) ? pyf1 : pyf0);
           const float ar = __builtin_amdgcn_exp2f(pair_p2(dx, dy, a.z, a.w, b.x, b.y));      // opacity * G
-          const bool ok = live && (ar >= ALPHA_MIN);        // (the clamp is above the threshold: same test on either)
+          // (the clamp is above the threshold: same test on either)
+          const bool ok = TESTED ? (live && (ar >= ALPHA_MIN)) : (ar >= thr[k]);
           // lanes that do not contribute run the same instructions on alpha = 0: 1 / (1 - 0) = 1 and every product is 0
           const float arm = ok ? ar : 0.0f;
           const float am = CLAMPED ? fminf(ALPHA_MAX, arm) : arm;
           const float rcp = __builtin_amdgcn_rcpf(1.0f - am);
           T[k] *= rcp;                                   // transmittance in front of this instance
-          const float cd = fmaf(cb, dpb[k], fmaf(b.w, dpg[k], b.z * dpr[k]));   // c . dL_dpix
+          const float D = fmaf(cb, dpb[k], fmaf(b.w, dpg[k], fmaf(b.z, dpr[k], -U[k])));   // c . dL_dpix - U
           const float dch = am * T[k];
-          const float dL_dalpha = fmaf(T[k], cd, -Bk[k] * rcp);
-          Bk[k] = fmaf(cd, dch, Bk[k]);
-          const float h = arm * dL_dalpha;               // opacity * G * dL_dalpha: the clamp passes the gradient on
+          // opacity * G * dL_dalpha with dL_dalpha = T D: the clamp passes the gradient on (arm, not am)
+          const float h = CLAMPED ? arm * (T[k] * D) : dch * D;
+          U[k] = fmaf(am, D, U[k]);
           // moments of h about the quad's first pixel: the offsets of the other three are 0 / 1, so h itself is all that
           // is added per pixel (dx_k = dx_0 - (k & 1) and dy_k = dy_0 - (k >> 1) exactly: all four differences are exact)
           S += h;
@@ -678,39 +671,8 @@ __device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, i
           v[3] = fmaf(dx0, v[1], fmaf(-dy0, Sx, Sxy));
           v[5] = S;
         }
-#if GSR_FOLD == 2
-        // transpose through LDS: every lane stores its nine partial sums, lane j < 9 of a row reads the 16 partials of
-        // value j of its row and adds them in a fixed tree -- then holds the row's sum of value j and adds it to the slab
-        {
-          float* xw = &L.xch[0][lane];
-#pragma unroll
-          for (int t = 0; t < 9; ++t) xw[t * XCH_ROW] = v[t];
-        }
-        __builtin_amdgcn_wave_barrier();      // LDS operations of one wave execute in order
-        if (q < 9) {
-          const float4* xr = reinterpret_cast<const float4*>(&L.xch[q][16 * grp]);
-          const float4 x0 = xr[0], x1 = xr[1], x2 = xr[2], x3 = xr[3];
-          const float nn = (((x0.x + x0.y) + (x0.z + x0.w)) + ((x1.x + x1.y) + (x1.z + x1.w))) +
-                           (((x2.x + x2.y) + (x2.z + x2.w)) + ((x3.x + x3.y) + (x3.z + x3.w)));
-          double* dst = L.slab + 9 * (e0 >> 4) + q;
-          if (!((clash >> i) & 1ull)) {
-            *dst += (double)nn;
-          } else {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              if (grp == g) *dst += (double)nn;
-              __builtin_amdgcn_wave_barrier();
-            }
-          }
-        }
-        __builtin_amdgcn_wave_barrier();      // the next step's stores follow this step's loads
-#else
         float n0, n1, n2;
-#if GSR_FOLD == 1
         row_fold9_masked(v, n0, n1, n2);
-#else
-        row_fold9(v, n0, n1, n2);
-#endif
         // lane j of bank k takes the bank's value of n0 (j = 0), n1 (j = 1), n2 (j = 2, bank 0 only): the nine sums of the
         // row sit in nine lanes and go to the slab with one read-add-write (LDS float atomics retire about one lane per
         // cycle per CU: far slower)
@@ -726,11 +688,14 @@ __device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, i
             __builtin_amdgcn_wave_barrier();     // LDS operations of one wave execute in order
           }
         }
-#endif
         e0 = e1;
       }
     };
-    if (clamp) walk(std::true_type{}); else walk(std::false_type{});
+    if (tested_round) {
+      if (clamp) walk(std::true_type{}, std::true_type{}); else walk(std::false_type{}, std::true_type{});
+    } else {
+      if (clamp) walk(std::true_type{}, std::false_type{}); else walk(std::false_type{}, std::false_type{});
+    }
     __builtin_amdgcn_wave_barrier();
     // one row per staged instance that received anything (all-zero sums: no row, the flag byte stays 0)
     if (m != 0u) {

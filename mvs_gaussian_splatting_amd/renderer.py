@@ -120,9 +120,12 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier:
     else:
         colors_precomp = override_color
 
+    # exactly the reference's eight keyword arguments (gaussian_renderer/__init__.py:257-265); the statistics request of
+    # this build travels as a ninth only when the caller asked for it
+    extra = {} if stats is None else {"densify_stats": stats}
     rendered_image, radii = rasterizer(means3D=xyz, means2D=screenspace_points, shs=shs,
                                        colors_precomp=colors_precomp, opacities=pc.get_opacity, scales=scales,
-                                       rotations=rotations, cov3D_precomp=cov3D_precomp, densify_stats=stats)
+                                       rotations=rotations, cov3D_precomp=cov3D_precomp, **extra)
     return {"render": rendered_image,
             "viewspace_points": screenspace_points,
             "visibility_filter": radii > 0,
