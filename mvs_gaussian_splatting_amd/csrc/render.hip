@@ -96,21 +96,30 @@ __device__ inline uint32_t subblock_mask(float gx, float gy, float ex, float ey,
 // The opacity rides in the exponent: alpha = opacity * exp(power) = exp2(log2(opacity) + log2e * power) -- the addend
 // of a multiply that becomes an fma, one instruction less per pair than the product (v_log_f32 is good to an ulp, the
 // sum is at most ~8 in magnitude: alpha moves by < 5e-7 relative).
+// Whether an instance can reach the 0.99 clamp (opacity > 0.99; alpha <= opacity otherwise, to the ulp of v_log / v_exp)
+// rides in the SIGN of the stored nkd: the evaluation takes -|nkd| (source modifiers: free), the clamped copies of the
+// walks read the sign.  The clamp is thus a property of the INSTANCE: which copy of a walk runs depends on what else
+// shares the round (256 instances in the forward, 64 in the backward), and an instance must get the same alpha in both
+// kernels whatever its neighbours are.
 struct LdsRec {
   float4 A;   // x, y, nka, kk
-  float4 B;   // nkd, log2(opacity), r, g
+  float4 B;   // +-|nkd| (+: opacity > 0.99), log2(opacity), r, g
 };
 __device__ inline void make_lds(const Staged& st, LdsRec& o) {
   o.A = make_float4(st.q0.x, st.q0.y, (-0.5f * LOG2E) * st.q0.z, st.kk);
-  o.B = make_float4((-0.5f * LOG2E) * st.isyy, __builtin_amdgcn_logf(st.q1.y), st.q1.z, st.q1.w);
+  const float nkd_abs = (0.5f * LOG2E) * fabsf(st.isyy);
+  o.B = make_float4(st.q1.y > ALPHA_MAX ? nkd_abs : -nkd_abs, __builtin_amdgcn_logf(st.q1.y), st.q1.z, st.q1.w);
+}
+__device__ __forceinline__ float clamp_alpha(float alpha, float nkd_signed) {
+  return nkd_signed > 0.0f ? fminf(ALPHA_MAX, alpha) : alpha;
 }
 // log2(alpha before the clamp).  The same five operations in the forward and in the backward: both must take the same
 // alpha >= 1/255 decisions
-__device__ __forceinline__ float pair_p2(float dx, float dy, float nka, float kk, float nkd, float lo) {
+__device__ __forceinline__ float pair_p2(float dx, float dy, float nka, float kk, float nkd_signed, float lo) {
 #pragma clang fp contract(off)
   const float u = __builtin_fmaf(kk, dy, dx);
   const float s = nka * u;
-  const float v = __builtin_fmaf(nkd * dy, dy, lo);
+  const float v = __builtin_fmaf(-fabsf(nkd_signed) * dy, dy, lo);
   return __builtin_fmaf(s, u, v);
 }
 
@@ -184,7 +193,7 @@ __device__ __forceinline__ void blend_pair(const float4 a, const float4 b, const
                                            uint32_t& last) {
   const float dx = a.x - pxf, dy = a.y - pyf;
   float alpha = __builtin_amdgcn_exp2f(pair_p2(dx, dy, a.z, a.w, b.x, b.y));
-  if (CLAMP) alpha = fminf(ALPHA_MAX, alpha);     // opacity <= 0.99 stays at or below 0.99 (to the ulp of v_log / v_exp): no clamp
+  if (CLAMP) alpha = clamp_alpha(alpha, b.x);
   if (alpha >= ALPHA_MIN) {
     const float test_T = __builtin_fmaf(-alpha, T, T);      // T (1 - alpha), rounded once
     if (!(test_T < T_STOP)) {
@@ -544,7 +553,7 @@ __device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, i
   }
 
   while (hi > 0) {
-    const uint32_t cur_lo = lo, hi_r = hi;      // this round: list positions cur_lo + 1 .. hi_r (1-based)
+    const uint32_t cur_lo = lo;
     const bool have = lo + lane < hi;
     // sub-blocks that still have a contributor in this round (1-based indices cur_lo + 1 .. hi)
     const uint32_t active = (sub_last[0] > cur_lo ? 1u : 0u) | (sub_last[1] > cur_lo ? 2u : 0u) |
@@ -599,26 +608,11 @@ __device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, i
       clash = __builtin_amdgcn_ballot_w64((a != dm && (a == b || a == c || a == d)) || (b != dm && (b == c || b == d)) ||
                                           (c != dm && c == d));
     }
-    // A pixel takes part from its last contributor on (walking back to front): position <= last[k].  That compare is
-    // needed per pair only in the round in which the pixel's last contributor lies strictly inside; in every other round
-    // the pixel is in for the whole round or out for the whole round, and the per-pixel alpha threshold says which
-    // (1/255, or +inf: the alpha test then fails for every instance and the pixel's state passes through untouched).
-    // TESTED = false is the walk for rounds without such a pixel: one compare per pair instead of two.
-    float thr[4];
-    bool waking = false;
-    uint32_t kmask = 0;       // quad positions with at least one pixel that is in for this round
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const bool in_all = last[k] >= hi_r, out_all = last[k] <= cur_lo;
-      waking = waking || !(in_all || out_all);
-      thr[k] = in_all ? ALPHA_MIN : __builtin_inff();
-      kmask |= (__builtin_amdgcn_ballot_w64(!out_all) != 0ull) ? (1u << k) : 0u;
-    }
-    const bool tested_round = __builtin_amdgcn_ballot_w64(waking) != 0ull;
-    // copies of the walk: the 0.99 clamp costs an instruction per pixel and almost no round needs it
-    auto walk = [&](auto clamped_c, auto tested_c) {
+    // two copies of the walk: the 0.99 clamp costs an instruction per pixel and almost no round needs it.  (A third copy
+    // for rounds in which no pixel's last contributor lies strictly inside -- a per-pixel alpha threshold of 1/255 or +inf
+    // instead of the position compare -- was measured: no gain, profiles/r03/ab_bwd_variants_c4.txt "thr".)
+    auto walk = [&](auto clamped_c) {
       constexpr bool CLAMPED = decltype(clamped_c)::value;
-      constexpr bool TESTED = decltype(tested_c)::value;
       uint32_t e0 = mylist[0];
       for (uint32_t i = 0; i < nmax; ++i) {
         const uint32_t e1 = mylist[i + 1];
@@ -633,26 +627,21 @@ __device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, i
         float S = 0.f, Sx = 0.f, Sy = 0.f, Sxy = 0.f;
   #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          bool live = true;
-          if (TESTED) {
-            live = pos1 <= last[k];
-            if (__builtin_amdgcn_ballot_w64(live) == 0ull) continue;    // every pixel of this quad position is past its last contributor
-          } else if (!((kmask >> k) & 1u)) {
-            continue;                                                   // ... for the whole round
-          }
+          const bool live = pos1 <= last[k];
+          if (__builtin_amdgcn_ballot_w64(live) == 0ull) continue;      // every pixel of this quad position is past its last contributor
           const float dx = a.x - ((k & 1) ? pxf1 : pxf0), dy = a.y - ((k >> 1) ? pyf1 : pyf0);
           const float ar = __builtin_amdgcn_exp2f(pair_p2(dx, dy, a.z, a.w, b.x, b.y));      // opacity * G
-          // (the clamp is above the threshold: same test on either)
-          const bool ok = TESTED ? (live && (ar >= ALPHA_MIN)) : (ar >= thr[k]);
+          const bool ok = live && (ar >= ALPHA_MIN);        // (the clamp is above the threshold: same test on either)
           // lanes that do not contribute run the same instructions on alpha = 0: 1 / (1 - 0) = 1 and every product is 0
           const float arm = ok ? ar : 0.0f;
-          const float am = CLAMPED ? fminf(ALPHA_MAX, arm) : arm;
+          const float am = CLAMPED ? clamp_alpha(arm, b.x) : arm;
           const float rcp = __builtin_amdgcn_rcpf(1.0f - am);
           T[k] *= rcp;                                   // transmittance in front of this instance
           const float D = fmaf(cb, dpb[k], fmaf(b.w, dpg[k], fmaf(b.z, dpr[k], -U[k])));   // c . dL_dpix - U
           const float dch = am * T[k];
-          // opacity * G * dL_dalpha with dL_dalpha = T D: the clamp passes the gradient on (arm, not am)
-          const float h = CLAMPED ? arm * (T[k] * D) : dch * D;
+          // opacity * G * dL_dalpha with dL_dalpha = T D: the clamp passes the gradient on (arm, not am).  Same
+          // association in both copies of the walk: which one an instance meets depends on what else is in its round
+          const float h = (CLAMPED ? arm * T[k] : dch) * D;
           U[k] = fmaf(am, D, U[k]);
           // moments of h about the quad's first pixel: the offsets of the other three are 0 / 1, so h itself is all that
           // is added per pixel (dx_k = dx_0 - (k & 1) and dy_k = dy_0 - (k >> 1) exactly: all four differences are exact)
@@ -691,11 +680,7 @@ __device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, i
         e0 = e1;
       }
     };
-    if (tested_round) {
-      if (clamp) walk(std::true_type{}, std::true_type{}); else walk(std::false_type{}, std::true_type{});
-    } else {
-      if (clamp) walk(std::true_type{}, std::false_type{}); else walk(std::false_type{}, std::false_type{});
-    }
+    if (clamp) walk(std::true_type{}); else walk(std::false_type{});
     __builtin_amdgcn_wave_barrier();
     // one row per staged instance that received anything (all-zero sums: no row, the flag byte stays 0)
     if (m != 0u) {
