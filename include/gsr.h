@@ -201,6 +201,11 @@ int gsr_debug_read_geom(const void* geom_ws, int32_t P, float* xy /*[P,2]*/, flo
 int gsr_debug_read_binning(const void* geom_ws, int32_t P, const void* bin_ws, uint32_t num_rendered,
                            uint32_t num_visible, int32_t width, int32_t height, int32_t binning_mode,
                            uint64_t* keys_sorted, uint32_t* point_list, void* stream);
+/* the device-side counters of a frame: out[0] num_rendered, [1] num_visible, [2] Gaussians with more than 64 instances
+ * (their gradient rows are pre-summed cooperatively), [3] reserved, [4] ~(smallest depth key), [5] largest depth key,
+ * [6] element count of the depth sort's top-digit pass (0: the frame's depths fit 24 key bits), [7] instances the binning
+ * workspace received (min(num_rendered, capacity)).  Synchronises the stream. */
+int gsr_debug_read_counts(const void* geom_ws, int32_t P, uint32_t out_host[8], void* stream);
 int gsr_debug_read_image(const void* img_ws, int32_t width, int32_t height, float* final_T,
                          uint32_t* n_contrib, uint32_t* ranges /*[T,2]*/, void* stream);
 

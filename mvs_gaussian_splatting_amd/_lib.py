@@ -75,6 +75,7 @@ SYMBOLS = {
     "gsr_debug_read_geom": (C.c_int, [C.c_void_p, C.c_int32] + [C.c_void_p] * 9),
     "gsr_debug_read_binning": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
                                          C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gsr_debug_read_counts": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint32), C.c_void_p]),
     "gsr_debug_read_image": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
     "gsr_l1_loss_workspace_bytes": (C.c_size_t, []),

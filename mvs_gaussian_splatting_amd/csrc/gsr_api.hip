@@ -622,6 +622,15 @@ int gsr_debug_read_binning(const void* geom_ws, int32_t P, const void* bin_ws, u
   return check(nullptr, s, "read_binning");
 }
 
+int gsr_debug_read_counts(const void* geom_ws, int32_t P, uint32_t out_host[8], void* stream) {
+  if (!geom_ws || !out_host || P < 0) return fail(GSR_E_BADARG, "bad geom_ws / out / P");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const GeomLayout L(P);
+  GSR_HIP(hipMemcpyAsync(out_host, at<uint32_t>(geom_ws, L.total), 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  GSR_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
 int gsr_debug_read_image(const void* img_ws, int32_t width, int32_t height, float* final_T, uint32_t* n_contrib,
                          uint32_t* ranges, void* stream) {
   if (!img_ws) return fail(GSR_E_BADARG, "img_ws is NULL");

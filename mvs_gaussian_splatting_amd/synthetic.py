@@ -184,6 +184,34 @@ class PipelineParams:
     fuse_densify_stats = False  # this build's extension: the backward also takes the densification statistics
 
 
+def make_heavy_tail_model(P: int, sh_degree: int, seed: int = 0, z_near: float = 0.3, z_far: float = 60.0,
+                          log_footprint_mean: float = math.log(0.0013), log_footprint_sigma: float = 0.95,
+                          opacity_mean: float = -0.5) -> "SyntheticGaussianModel":
+    """A cloud shaped like a TRAINED scene rather than the uniform box of SURVEY §8(d): depths log-uniform over more
+    than seven binades (so a frame needs all 32 bits of the depth key), a third of the Gaussians in dense blobs
+    (per-tile lists thousands long), world-space scales proportional to depth times a log-normal factor with a heavy tail
+    (most footprints a few pixels, a few covering hundreds of tiles: instances per Gaussian ~6-10 at 1080p, rects above
+    the packed-payload and tile-mask limits, Gaussians with more than 64 gradient rows), anisotropic axes, and opacities
+    from transparent to opaque.  Camera: the identity view of ``orbit_camera(0, ...)`` looking down +z."""
+    g = torch.Generator().manual_seed(seed)
+    m = SyntheticGaussianModel(P, sh_degree, seed=seed)
+    z = torch.exp(torch.rand(P, generator=g) * (math.log(z_far) - math.log(z_near)) + math.log(z_near))
+    # positions on the screen: uniform over a frustum a little wider than the image (tan half-fov 0.8 x 0.45 at 1080p)
+    xy = (torch.rand(P, 2, generator=g) * 2 - 1) * torch.tensor([0.95, 0.55])
+    n_blob = P // 3
+    centres = torch.tensor([[0.25, -0.1, 4.0], [-0.4, 0.15, 9.0], [0.05, 0.2, 2.0]])
+    which = torch.randint(0, 3, (n_blob,), generator=g)
+    blob = centres[which] + torch.randn(n_blob, 3, generator=g) * torch.tensor([0.06, 0.05, 0.08])
+    xy[:n_blob] = blob[:, :2]
+    z[:n_blob] = blob[:, 2].clamp(min=z_near)
+    m._xyz = torch.stack([xy[:, 0] * z, xy[:, 1] * z, z], dim=1).contiguous()
+    foot = torch.exp(log_footprint_mean + log_footprint_sigma * torch.randn(P, 1, generator=g))      # tan-space size
+    aniso = torch.exp(0.5 * torch.randn(P, 3, generator=g))
+    m._scaling = torch.log(z[:, None] * foot * aniso).contiguous()
+    m._opacity = (2.0 * torch.randn(P, 1, generator=g) + opacity_mean).contiguous()
+    return m
+
+
 def make_scene(cfg: SceneConfig, seed: int = 0, device="cpu", P: Optional[int] = None, view: int = 0,
                n_views: int = 8):
     """(model, camera, bg, target image) for a config; ``P`` overrides the Gaussian count."""

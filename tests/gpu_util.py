@@ -86,6 +86,8 @@ def forward_with_state(dev, settings, means3D, opacities, shs=None, colors_preco
         ranges = torch.empty(gx * gy, 2, dtype=torch.int32, device=dev)
         _lib.check(lib.gsr_debug_read_image(img.data_ptr(), W, H, final_T.data_ptr(), n_contrib.data_ptr(),
                                             ranges.data_ptr(), stream), "read_img")
+        cnt = (C.c_uint32 * 8)()
+        _lib.check(lib.gsr_debug_read_counts(geom.data_ptr(), P, cnt, stream), "read_counts")
         stats = None
         if want_stats and R > 0:      # work counters of the forward compositing kernel (re-runs it with counting on)
             st8 = torch.zeros(8, dtype=torch.int64, device=dev)
@@ -98,7 +100,7 @@ def forward_with_state(dev, settings, means3D, opacities, shs=None, colors_preco
             assert torch.equal(scratch, color)
         torch.cuda.synchronize(dev)
     del keep
-    return {"stats": stats, "color": color.cpu(), "radii": radii.cpu(), "R": R, "V": V, "xy": xy.cpu(), "conic_opacity": con.cpu(),
+    return {"counts": [int(v) for v in cnt], "stats": stats, "color": color.cpu(), "radii": radii.cpu(), "R": R, "V": V, "xy": xy.cpu(), "conic_opacity": con.cpu(),
             "rgb": rgb.cpu(), "depth": depth.cpu(), "tiles": tiles.cpu().numpy().astype(np.int64),
             "offsets": offs.cpu().numpy().view(np.uint32), "rect": rect.cpu().numpy().astype(np.int64),
             "clamped": clamped.cpu().numpy(), "keys": keys[:R].cpu().numpy().view(np.uint64),
