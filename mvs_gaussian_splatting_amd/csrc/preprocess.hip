@@ -573,41 +573,58 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(GsrParams p, 
   const bool vis = valid && radii[idx] > 0;
   const int wave_first = blockIdx.x * PRE_BLOCK + wid * WAVE;
   const int rows_valid = min(WAVE, p.P - wave_first);
-  if (split) {
-    // dL/df_rest rows are staged in LDS (row stride 45) and streamed out with 16-byte stores
-    float* st = sh_stage[wid];
-    my_row = st + lane * REST_ROW;
-    if (!vis) {
-#pragma unroll
-      for (int k = 0; k < REST_ROW; ++k) my_row[k] = 0.0f;
-      if (valid) { g.dL_dshs[3 * (size_t)idx] = 0.f; g.dL_dshs[3 * (size_t)idx + 1] = 0.f; g.dL_dshs[3 * (size_t)idx + 2] = 0.f; }
-    }
-  } else if (sh_lds && !vis) {
-#pragma unroll
-    for (int k = 0; k < 48; ++k) my_row[k] = 0.0f;
-  }
-
   // ---- (0) deterministic sum of this Gaussian's instance rows ---------------------------------------------------
   // A splat that covers more than ROWS_COOP tiles (thousands, for a large one) was folded into its first row by
   // sum_big_rows_kernel: a single lane walking thousands of flag bytes stalls its whole wave.
   GeomRec r;
   float dcxx = 0.f, dcxy = 0.f, dcyy = 0.f;
+  bool any_row = false;
   if (vis) {
     r = rec[idx];
     const uint32_t n_all = bin_count(r.rect_wh, r.tile_mask);
     const uint32_t n_rows = n_all > ROWS_COOP ? 1u : n_all;
     const uint32_t slot0 = slot_base[idx];
-    for (uint32_t k = 0; k < n_rows; ++k) {
-      const uint32_t s = slot0 + k;
-      if (row_flags[s]) {
-        const GradRow q = rows[s];
-        dm2x += q.dmx; dm2y += q.dmy; dcxx += q.dcxx; dcxy += q.dcxy; dcyy += q.dcyy;
-        dop += q.dop; dcol[0] += q.dr; dcol[1] += q.dg; dcol[2] += q.db;
-      }
+    // ROW_BATCH rows per trip to memory: the flag bytes of a batch are requested together, then the flagged rows -- the
+    // additions stay in slot order (bitwise reproducible).  One row per iteration made every row two dependent
+    // round-trips; a heavy-tailed scene (5-6 rows per Gaussian, up to ROWS_COOP) spent most of this kernel there.
+    constexpr uint32_t ROW_BATCH = 4;
+    for (uint32_t k = 0; k < n_rows; k += ROW_BATCH) {
+      uint8_t f[ROW_BATCH];
+      GradRow q[ROW_BATCH];
+#pragma unroll
+      for (uint32_t u = 0; u < ROW_BATCH; ++u) f[u] = k + u < n_rows ? row_flags[slot0 + k + u] : (uint8_t)0;
+#pragma unroll
+      for (uint32_t u = 0; u < ROW_BATCH; ++u)
+        if (f[u]) q[u] = rows[slot0 + k + u];
+#pragma unroll
+      for (uint32_t u = 0; u < ROW_BATCH; ++u)
+        if (f[u]) {
+          any_row = true;
+          dm2x += q[u].dmx; dm2y += q[u].dmy; dcxx += q[u].dcxx; dcxy += q[u].dcxy; dcyy += q[u].dcyy;
+          dop += q[u].dop; dcol[0] += q[u].dr; dcol[1] += q[u].dg; dcol[2] += q[u].db;
+        }
     }
   }
 
-  if (vis) {
+  // A visible Gaussian that received no row (behind saturated pixels, or below 1/255 everywhere) has every sum zero and
+  // therefore every gradient zero: it takes the path of an invisible one -- zeros are written, and its position /
+  // scale / rotation / SH row (296 bytes) are not read.
+  const bool active = vis && any_row;
+  if (split) {
+    // dL/df_rest rows are staged in LDS (row stride 45) and streamed out with 16-byte stores
+    float* st = sh_stage[wid];
+    my_row = st + lane * REST_ROW;
+    if (!active) {
+#pragma unroll
+      for (int k = 0; k < REST_ROW; ++k) my_row[k] = 0.0f;
+      if (valid) { g.dL_dshs[3 * (size_t)idx] = 0.f; g.dL_dshs[3 * (size_t)idx + 1] = 0.f; g.dL_dshs[3 * (size_t)idx + 2] = 0.f; }
+    }
+  } else if (sh_lds && !active) {
+#pragma unroll
+    for (int k = 0; k < 48; ++k) my_row[k] = 0.0f;
+  }
+
+  if (active) {
     {
       // the rows carry the first moments M = sum h * (mean - pixel); the conic is the same for every tile of the
       // Gaussian, so dL/dmean2D = -0.5 * (W, H) .* (conic M) is applied once here instead of per pixel pair

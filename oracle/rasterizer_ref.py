@@ -386,7 +386,8 @@ COND_EPS = 2.5e-7   # ~4 ulp(float32): rounding of the three products, their sum
 
 def render_tiles_ref(pre: Dict[str, torch.Tensor], point_list: np.ndarray, ranges: np.ndarray,
                      settings: RasterSettings, *, tiles: Optional[Sequence[int]] = None,
-                     chunk: int = 256, upstream_grad: bool = True, want_margin: bool = False):
+                     chunk: int = 256, upstream_grad: bool = True, want_margin: bool = False,
+                     guard_stats: Optional[dict] = None):
     """Front-to-back alpha compositing per 16x16 tile (A.4).  ``tiles`` restricts the work
     to a subset (used for the bounded CPU-baseline sample); untouched pixels stay 0.
 
@@ -399,6 +400,10 @@ def render_tiles_ref(pre: Dict[str, torch.Tensor], point_list: np.ndarray, range
     orders (fma contraction, pre-scaled coefficients) differ by ~1e-7 x (sum of |terms|) in
     ``power`` and by as much, relatively, in alpha; the pixel is robust only while the blended
     bound sum_i w_i * COND_EPS * (|terms|_i) stays below 3e-6 (COND_EPS = 4 float32 ulps).
+
+    ``guard_stats`` (a dict, filled in place): how often upstream's ``power > 0 -> skip`` guard (A.4) fired on a pair the
+    pixel was still considering -- ``pairs`` (count) and ``pix`` (bool [H,W]: pixels with at least one such pair).  The
+    true exponent is never positive; the guard only fires on the rounding noise of this expanded three-term form.
     """
     dt = pre["v_xy"].dtype
     H, W = int(settings.image_height), int(settings.image_width)
@@ -416,6 +421,8 @@ def render_tiles_ref(pre: Dict[str, torch.Tensor], point_list: np.ndarray, range
     final_T = torch.ones(Hp, Wp, dtype=dt)
     n_contrib = torch.zeros(Hp, Wp, dtype=torch.int32)
     margin = torch.full((Hp, Wp), float("inf"), dtype=dt) if want_margin else None
+    guard_pix = torch.zeros(Hp, Wp, dtype=torch.bool) if guard_stats is not None else None
+    guard_pairs = 0
 
     lx = torch.arange(TILE).repeat(TILE)
     ly = torch.arange(TILE).repeat_interleave(TILE)
@@ -456,6 +463,13 @@ def render_tiles_ref(pre: Dict[str, torch.Tensor], point_list: np.ndarray, range
             C = C + torch.einsum("np,nc->cp", w, g_rgb)
             n_live = live.sum(dim=0)
             has = n_live > 0
+            if guard_stats is not None:
+                with torch.no_grad():
+                    before = torch.cat([(~done)[None, :], live[:-1]], 0)      # the pixel was still composing at this entry
+                    fired = (power > 0) & before
+                    guard_pairs += int(fired.sum())
+                    gp = fired.any(dim=0).reshape(TILE, TILE)
+                    guard_pix[ty * TILE:(ty + 1) * TILE, tx * TILE:(tx + 1) * TILE] |= gp
             T_new = cp.gather(0, (n_live - 1).clamp(min=0)[None, :])[0]
             T = torch.where(has, T_new, T)
             ar = torch.arange(1, n + 1)[:, None] + (pos - s)
@@ -493,13 +507,16 @@ def render_tiles_ref(pre: Dict[str, torch.Tensor], point_list: np.ndarray, range
     res = (color, final_T[:H, :W], n_contrib[:H, :W])
     if want_margin:
         res = res + (margin[:H, :W],)
+    if guard_stats is not None:
+        guard_stats["pairs"] = guard_pairs
+        guard_stats["pix"] = guard_pix[:H, :W]
     return res
 
 
 def rasterize_ref(means3D: torch.Tensor, means2D: Optional[torch.Tensor], opacities: torch.Tensor,
                   settings: RasterSettings, *, shs=None, colors_precomp=None, scales=None, rotations=None,
                   cov3D_precomp=None, upstream_grad: bool = True, want_margin: bool = False,
-                  tiles: Optional[Sequence[int]] = None, want_aux: bool = False):
+                  tiles: Optional[Sequence[int]] = None, want_aux: bool = False, guard_stats: Optional[dict] = None):
     """Whole operator: returns ``(color[3,H,W], radii[P] int32)`` like the reference call at
     ``gaussian_renderer/__init__.py:257-265`` (plus an aux dict when ``want_aux``)."""
     pre = preprocess_ref(means3D, opacities, settings, shs=shs, colors_precomp=colors_precomp,
@@ -507,7 +524,7 @@ def rasterize_ref(means3D: torch.Tensor, means2D: Optional[torch.Tensor], opacit
                          means2D=means2D, upstream_grad=upstream_grad)
     keys, plist, ranges = bin_ref(pre)
     out = render_tiles_ref(pre, plist, ranges, settings, tiles=tiles, upstream_grad=upstream_grad,
-                           want_margin=want_margin)
+                           want_margin=want_margin, guard_stats=guard_stats)
     if want_aux:
         aux = {"pre": pre, "keys": keys, "point_list": plist, "ranges": ranges,
                "final_T": out[1], "n_contrib": out[2]}
