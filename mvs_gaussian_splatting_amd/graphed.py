@@ -1,0 +1,182 @@
+"""Forward-only rendering of a FIXED model through one captured HIP graph per camera format.
+
+``render.py`` of the reference (``render.py:32-40``) renders a trained model from a list of cameras: the parameters do
+not change, only the view does.  At 100 k Gaussians (BASELINE config 2) the ~27 kernels of a frame take 0.19 ms on
+the GPU but ~0.27 ms to ISSUE from Python one by one.  ``GraphedRenderer`` issues them once: the whole frame
+(``gsr_forward``: no host round-trip, every launch sized for a capacity, counts read on the device) is captured into a
+HIP graph (``torch.cuda.CUDAGraph``) whose inputs live in static buffers; a frame is then three small copies (view
+matrix, projection matrix, camera centre) and one graph launch.
+
+    gr = GraphedRenderer(gaussians, pipe, background)
+    for cam in cameras:
+        img = gr.render(cam)["render"]          # valid until the next render() -- clone() to keep it
+
+The graph fixes everything passed by value: image size, tan(FoV/2), SH degree, scale modifier.  One graph is kept per
+such format (cameras of one dataset share it).  Training cannot use this class: the backward needs each frame's
+workspaces, which the next replay overwrites.
+
+Capacity: the first frame of a format runs eagerly (with the count read-back) and sizes the binning workspace at 1.5 x
+its instance count.  Every later frame's real count lands in pinned memory and is compared with the capacity when the
+next frame is requested, in ``check()``, or at once with ``render(..., verify=True)``; an overflowed frame is re-rendered
+with a larger workspace (nothing is lost: the inputs are still there) -- ``verify=True`` therefore always returns a
+complete image, the default returns the previous frame's verdict one call late and raises ``GsrError`` if that frame was
+incomplete.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from .rasterizer import GaussianRasterizationSettings, _make_params, _round_ws
+from .renderer import _can_fuse
+
+
+class _Format:
+    """One captured graph: static inputs / outputs / workspaces for an (H, W, tanfovx, tanfovy, degree) combination."""
+
+    def __init__(self):
+        self.graph = None
+        self.capacity = 0
+        self.pending = False        # a replay whose count has not been compared with the capacity yet
+        self.frames = 0
+
+
+class GraphedRenderer:
+    def __init__(self, pc, pipe, bg_color: torch.Tensor, scaling_modifier: float = 1.0):
+        if not pc.get_xyz.is_cuda:
+            raise _lib.GsrError("GraphedRenderer needs the model on a ROCm GPU (no CPU path)")
+        if getattr(pipe, "debug", False):
+            raise ValueError("debug mode synchronises after every kernel: not capturable")
+        self.lib = _lib.load()
+        self.dev = pc.get_xyz.device
+        self.scaling_modifier = float(scaling_modifier)
+        self.sh_degree = int(pc.active_sh_degree)
+        self.bg = bg_color.detach().to(self.dev, torch.float32).contiguous().clone()
+        empty = torch.empty(0, dtype=torch.float32, device=self.dev)
+        with torch.no_grad():
+            # the operator inputs, taken ONCE (the model is fixed): raw parameters where the kernels can apply the
+            # activations themselves, the getters' results otherwise
+            self.P = int(pc.get_xyz.shape[0])
+            if _can_fuse(pc, pipe, None):
+                self.fused = True
+                self.inputs = dict(means3D=pc.get_xyz.detach().contiguous(), sh=pc._features_dc.detach().contiguous(),
+                                   colors_precomp=empty, opacities=pc._opacity.detach().contiguous(),
+                                   scales=pc._scaling.detach().contiguous(), rotations=pc._rotation.detach().contiguous(),
+                                   cov3Ds_precomp=empty, sh_rest=pc._features_rest.detach().contiguous())
+                self.act_flags = _lib.ACT_SCALE_EXP | _lib.ACT_ROT_NORMALIZE | _lib.ACT_OPACITY_SIGMOID
+            else:
+                self.fused = False
+                self.inputs = dict(means3D=pc.get_xyz.detach().contiguous(), sh=pc.get_features.detach().contiguous().clone(),
+                                   colors_precomp=empty, opacities=pc.get_opacity.detach().contiguous().clone(),
+                                   scales=pc.get_scaling.detach().contiguous().clone(),
+                                   rotations=pc.get_rotation.detach().contiguous().clone(), cov3Ds_precomp=empty, sh_rest=None)
+                self.act_flags = 0
+        self.formats: Dict[tuple, _Format] = {}
+
+    # ---- one format ----------------------------------------------------------------------------------------------
+    def _build(self, key, cam) -> _Format:
+        H, W, tanx, tany = key
+        lib, dev, P = self.lib, self.dev, self.P
+        f = _Format()
+        f.view = torch.empty(4, 4, dtype=torch.float32, device=dev)
+        f.proj = torch.empty(4, 4, dtype=torch.float32, device=dev)
+        f.campos = torch.empty(3, dtype=torch.float32, device=dev)
+        f.settings = GaussianRasterizationSettings(H, W, tanx, tany, self.bg, self.scaling_modifier, f.view, f.proj,
+                                                   self.sh_degree, f.campos, False, False)
+        i = self.inputs
+        f.params, f.keep = _make_params(dev, f.settings, i["means3D"], i["sh"], i["colors_precomp"], i["opacities"],
+                                        i["scales"], i["rotations"], i["cov3Ds_precomp"], sh_rest=i["sh_rest"],
+                                        act_flags=self.act_flags, forward_only=True)
+        f.params.profile = None
+        f.pinned = torch.zeros(16, dtype=torch.int32).pin_memory()
+        f.params.counts_pinned = f.pinned.data_ptr()
+        f.geom = torch.empty(lib.gsr_geom_bytes(P), dtype=torch.uint8, device=dev)
+        f.img = torch.empty(lib.gsr_image_bytes(W, H), dtype=torch.uint8, device=dev)
+        f.radii = torch.zeros(P, dtype=torch.int32, device=dev)
+        f.color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+        f.binning = None
+        self._set_camera(f, cam)
+        # first frame: eager, with the count read-back -> capacity
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        R, V = C.c_uint32(0), C.c_uint32(0)
+        _lib.check(lib.gsr_forward_preprocess(C.byref(f.params), f.geom.data_ptr(), f.radii.data_ptr(), stream,
+                                              C.byref(R), C.byref(V)), "gsr_forward_preprocess")
+        self._capture(f, max(int(R.value), 1))
+        return f
+
+    def _capture(self, f: _Format, need: int) -> None:
+        lib, dev = self.lib, self.dev
+        H, W = f.settings.image_height, f.settings.image_width
+        f.capacity = (int(need * 1.5) + (1 << 20)) >> 20 << 20
+        nbytes = lib.gsr_binning_bytes(f.capacity, self.P, W, H, f.params.binning_mode)
+        f.binning = torch.empty(_round_ws(nbytes), dtype=torch.uint8, device=dev)
+        f.nbytes = nbytes
+        if f.params.binning_mode == _lib.BINNING_KEYS64:
+            raise _lib.GsrError("GraphedRenderer needs a two-level binning mode (gsr_forward)")
+        torch.cuda.synchronize(dev)
+        f.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(f.graph):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.gsr_forward(C.byref(f.params), f.geom.data_ptr(), f.binning.data_ptr(), f.nbytes, f.capacity,
+                                       f.img.data_ptr(), f.radii.data_ptr(), f.color.data_ptr(), None, stream),
+                       "gsr_forward (graph capture)")
+        f.done = torch.cuda.Event()
+        f.pending = False
+
+    def _set_camera(self, f: _Format, cam) -> None:
+        f.view.copy_(cam.world_view_transform, non_blocking=True)
+        f.proj.copy_(cam.full_proj_transform, non_blocking=True)
+        f.campos.copy_(cam.camera_center, non_blocking=True)
+
+    def _verdict(self, f: _Format) -> bool:
+        """Wait for the pending replay and compare its instance count with the capacity.  True: the frame is complete."""
+        if not f.pending:
+            return True
+        f.done.synchronize()
+        f.pending = False
+        f.last_counts = (int(f.pinned[0]) & 0xffffffff, int(f.pinned[1]) & 0xffffffff)
+        return f.last_counts[0] <= f.capacity
+
+    # ---- public ----------------------------------------------------------------------------------------------------
+    def render(self, viewpoint_camera, verify: bool = False) -> dict:
+        """One frame.  The tensors of the result are STATIC buffers, overwritten by the next call for the same camera
+        format.  ``verify=True`` waits for the frame and re-renders it if its instance count exceeded the capacity."""
+        key = (int(viewpoint_camera.image_height), int(viewpoint_camera.image_width),
+               math.tan(viewpoint_camera.FoVx * 0.5), math.tan(viewpoint_camera.FoVy * 0.5))
+        with torch.cuda.device(self.dev):
+            f = self.formats.get(key)
+            if f is None:
+                f = self.formats[key] = self._build(key, viewpoint_camera)
+            elif not self._verdict(f):
+                need = f.last_counts[0]
+                self._capture(f, need)
+                raise _lib.GsrError(f"the previous graphed frame overflowed its binning capacity ({need} instances): its "
+                                    "image was incomplete; the graph has been rebuilt with a larger workspace "
+                                    "(render(..., verify=True) re-renders such a frame instead)")
+            self._set_camera(f, viewpoint_camera)
+            f.graph.replay()
+            f.done.record()
+            f.pending = True
+            f.frames += 1
+            if verify and not self._verdict(f):
+                self._capture(f, f.last_counts[0])
+                f.graph.replay()
+                f.done.record()
+                f.pending = True
+                if not self._verdict(f):      # cannot happen: the capacity now exceeds this very frame's count
+                    raise _lib.GsrError("graphed frame overflowed twice")
+        return {"render": f.color, "viewspace_points": None, "visibility_filter": f.radii > 0, "radii": f.radii,
+                "selected_pts_mask": None}
+
+    def check(self) -> None:
+        """Block until every issued frame has been checked; raises GsrError if the last frame of a format overflowed."""
+        with torch.cuda.device(self.dev):
+            for f in self.formats.values():
+                if not self._verdict(f):
+                    need = f.last_counts[0]
+                    self._capture(f, need)
+                    raise _lib.GsrError(f"a graphed frame overflowed its binning capacity ({need} instances); graph rebuilt")
