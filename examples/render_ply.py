@@ -9,7 +9,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from mvs_gaussian_splatting_amd import render  # noqa: E402
+from mvs_gaussian_splatting_amd.graphed import GraphedRenderer  # noqa: E402
 from mvs_gaussian_splatting_amd.ply_io import load_ply  # noqa: E402
 from mvs_gaussian_splatting_amd.synthetic import PipelineParams, orbit_camera  # noqa: E402
 
@@ -45,10 +45,14 @@ def render_set(ply_path, out_dir, n_views=8, width=256, height=160, focal=220.0,
     bg = torch.zeros(3, device=dev)
     os.makedirs(out_dir, exist_ok=True)
     images = []
+    # a fixed model seen from many cameras: the frame is captured once as a HIP graph and replayed per camera;
+    # verify=True checks every frame's instance count against the workspace before the image is trusted (and re-renders
+    # it if the count grew beyond it), which is what a renderer that writes every frame to disk wants
+    renderer = GraphedRenderer(model, PipelineParams(), bg)
     with torch.no_grad():                                       # render.py:38
         for v in range(n_views):
             cam = orbit_camera(v, n_views, width, height, focal, focal, centre=centre, device=dev)
-            images.append(render(cam, model, PipelineParams(), bg)["render"])
+            images.append(renderer.render(cam, verify=True)["render"].clone())
             write_ppm(os.path.join(out_dir, f"{v:05d}.ppm"), images[-1])
     return model, images
 

@@ -45,6 +45,8 @@ def make_problem(dev, P=4000, W=256, H=160, n_views=8, seed=0):
     lrs = {"xyz": 1.6e-4, "f_dc": 2e-2, "f_rest": 1e-3, "opacity": 0.05, "scaling": 5e-3, "rotation": 1e-3}
     model.optimizer = torch.optim.Adam([{"params": [getattr(model, a)], "lr": lrs[k], "name": k}
                                         for k, a in GROUP_ATTR.items()], lr=0.0, eps=1e-15)
+    pipe.fuse_densify_stats = True      # the backward takes the densification statistics; add_densification_stats below
+                                        # stays where the reference has it and recognises such a frame
     return targets, cams, bg, pipe, model
 
 

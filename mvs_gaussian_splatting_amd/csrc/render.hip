@@ -106,7 +106,10 @@ struct LdsRec {
   float4 B;   // +-|nkd| (+: opacity > 0.99), log2(opacity), r, g
 };
 __device__ inline void make_lds(const Staged& st, LdsRec& o) {
-  o.A = make_float4(st.q0.x, st.q0.y, (-0.5f * LOG2E) * st.q0.z, st.kk);
+  // -|cxx|: a covariance whose float32 determinant came out negative (a needle thousands of pixels long) yields a
+  // negative conic; upstream's power > 0 guard drops most pairs of such a splat, here it composes with |cxx| instead.
+  // What matters is that alpha stays <= opacity: an alpha above 1 would un-park a saturated pixel (T (1 - alpha) > 0)
+  o.A = make_float4(st.q0.x, st.q0.y, (-0.5f * LOG2E) * fabsf(st.q0.z), st.kk);
   const float nkd_abs = (0.5f * LOG2E) * fabsf(st.isyy);
   o.B = make_float4(st.q1.y > ALPHA_MAX ? nkd_abs : -nkd_abs, __builtin_amdgcn_logf(st.q1.y), st.q1.z, st.q1.w);
 }

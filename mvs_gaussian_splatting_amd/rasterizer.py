@@ -206,11 +206,25 @@ def _state_for(key) -> _CapacityState:
         return st
 
 
+_RING = 64                  # frames that may be in flight unchecked; the host waits for the oldest beyond that
+_ring_store: list = []      # the one pinned allocation behind the slots (pin_memory() costs ~1 ms: never per frame)
+
+
 def _pinned_slot() -> torch.Tensor:
-    with _defer_lock:
-        if _free_slots:
-            return _free_slots.pop()
-    return torch.zeros(16, dtype=torch.int32).pin_memory()
+    """A 64-byte slice of one pinned block for the counts of a frame.  When all slots are out, the oldest pending frame
+    is checked (blocking) to get its slot back."""
+    while True:
+        with _defer_lock:
+            if not _ring_store:
+                block = torch.zeros(_RING, 16, dtype=torch.int32).pin_memory()
+                _ring_store.append(block)
+                _free_slots.extend(block[i] for i in range(_RING))
+            if _free_slots:
+                return _free_slots.pop()
+            oldest = _pending[0] if _pending else None
+        if oldest is None:
+            raise _lib.GsrError("pinned count slots exhausted with nothing pending")
+        _verify(oldest, block=True)
 
 
 def _new_event() -> int:

@@ -17,3 +17,5 @@ for k in ("roofline", "roofline_step"):
 print({k: v["avg_ms"] for k, v in j["roofline_by_kernel"].items()})
 print(j["cpu_baseline"]["value"], j["cpu_baseline"].get("train_step_ms"))
 PY
+PYTHONPATH=.:tools timeout -k 10 200 python tools/bench_graphed.py C2 300 2>&1 | grep -v amdgpu.ids | tee $OUT/graphed_c2.txt
+PYTHONPATH=.:tools timeout -k 10 200 python tools/bench_graphed.py C3 100 2>&1 | grep -v amdgpu.ids | tee $OUT/graphed_c3.txt

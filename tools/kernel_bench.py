@@ -11,6 +11,7 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 cfg = args[0] if len(args) > 0 else "C4"
 iters = int(args[1]) if len(args) > 1 else 10
 s = GpuScene(cfg, fused="--fused" in sys.argv)       # --fused: raw parameters + split SH, as render() feeds them
+s.fuse_stats = "--stats" in sys.argv                 # --stats: the backward also takes the densification statistics
 dL = torch.sign(torch.rand(3, s.H, s.W, device=s.dev) - 0.5) / (3 * s.H * s.W)
 for _ in range(2):
     s.forward(); s.backward(dL)

@@ -84,8 +84,12 @@ class GpuScene:
             else:
                 self.g = [new(P, 3), new(P, 3), new(P, 16, 3), new(P, 1), new(P, 3), new(P, 4)]
                 rest = None
+            st = [None, None, None]
+            if getattr(self, "fuse_stats", False):     # densification statistics taken by preprocess_bwd's epilogue
+                self.stats = [torch.zeros(P, device=dev) for _ in range(3)]
+                st = [t.data_ptr() for t in self.stats]
             self.grads = _lib.GsrGrads(self.g[0].data_ptr(), self.g[1].data_ptr(), self.g[2].data_ptr(), None,
-                                       self.g[3].data_ptr(), self.g[4].data_ptr(), self.g[5].data_ptr(), None, rest)
+                                       self.g[3].data_ptr(), self.g[4].data_ptr(), self.g[5].data_ptr(), None, rest, *st)
         nb = lib.gsr_backward_bytes(P, self.R)
         if not hasattr(self, "bwd_ws") or self.bwd_ws.numel() < nb:
             self.bwd_ws = torch.empty(nb, dtype=torch.uint8, device=dev)
