@@ -170,6 +170,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true",
                     help="feed the operator through the reference getters (cat/exp/normalize/sigmoid in torch)")
+    ap.add_argument("--fuse-stats", action="store_true",
+                    help="take the densification statistics in preprocess_bwd's epilogue instead of the stand-alone kernel")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
     # stdout carries exactly one line, the JSON result: native libraries (the RCCL / gloo banners) write to fd 1 too,
@@ -241,9 +243,10 @@ def main():
         p.requires_grad_(True)
     pipe = PipelineParams()
     pipe.fuse_activations = not args.unfused
-    # the densification statistics are taken inside the backward (GsrGrads.stats_*); the add_densification_stats call of
-    # the reference's loop stays where it is and recognises the frame (--unfused: stand-alone kernel, as the reference)
-    pipe.fuse_densify_stats = not args.unfused
+    # densification statistics: the stand-alone kernel of add_densification_stats (45 us).  The epilogue fused into
+    # preprocess_bwd (GsrGrads.stats_*, --fuse-stats) is slower on this part: the three extra read-modify-write streams
+    # cost the bandwidth-bound kernel 55-70 us (profiles/r03/ab_densify_stats.txt)
+    pipe.fuse_densify_stats = bool(args.fuse_stats)
     W, H = cfg.width, cfg.height
     M = (cfg.sh_degree + 1) ** 2
 
@@ -296,8 +299,8 @@ def main():
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             all_reduce(t, dist.ReduceOp.MAX)
             dt = float(t.item())
-        per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(k))
-        return dt, per_step
+        in_order = [evs[i].elapsed_time(evs[i + 1]) for i in range(k)]
+        return dt, (sorted(in_order), in_order)
 
     def pct(v, q):
         return round(v[min(len(v) - 1, int(q * len(v)))], 4)
@@ -319,11 +322,17 @@ def main():
         return 10 * 2 * 4 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
     K = args.steps
+    # Headline regions: EXACTLY K steps each, nothing but the steps between the barriers.
+    t_fwd, (fwd_steps, fwd_order) = timed(fwd_step, K)
+    t_train, (train_steps, train_order) = timed(train_step, K)
+    # Per-kernel times for the roofline objects: the same K + K steps once more with the library's stage timers on (a HIP
+    # event pair around every stage, on the stream the kernels run on).  Kept out of the headline regions because the
+    # 14-16 event records per frame cost the frame 5-10 % (they serialise the stream: `profiled_*_ms` below shows it).
     prof = _lib.StageProfile()
     with prof:
-        t_fwd, fwd_steps = timed(fwd_step, K)
+        t_fwd_prof, _ = timed(fwd_step, K)
         stages_fwd = prof.collect()
-        t_train, train_steps = timed(train_step, K)
+        t_train_prof, _ = timed(train_step, K)
         stages_train = prof.collect()
     prof.close()
     # The literal drop-in (INTEGRATION.md option A: the reference's own render() feeding the operator through the
@@ -335,7 +344,7 @@ def main():
     unfused = None
     if pipe.fuse_activations and world == 1:
         pipe.fuse_activations = False
-        pipe.fuse_densify_stats = False
+        fuse_stats_was, pipe.fuse_densify_stats = pipe.fuse_densify_stats, False
         k2 = max(3, K // 4)
         for _ in range(2):
             fwd_step(); train_step()
@@ -344,7 +353,7 @@ def main():
         unfused = {"unfused_fwd_ms": round(t_uf / k2 * 1e3, 3), "unfused_train_ms": round(t_ut / k2 * 1e3, 3),
                    "unfused_steps": k2}
         pipe.fuse_activations = True
-        pipe.fuse_densify_stats = True
+        pipe.fuse_densify_stats = fuse_stats_was
 
     # instances of this rank's view: read back from the stage the operator itself ran
     from mvs_gaussian_splatting_amd.rasterizer import frame_counts
@@ -468,6 +477,8 @@ def main():
             "ms_per_step": round(train_ms, 3), "fwd_ms_per_step": round(fwd_ms, 3),
             "train_mpixels_per_s": round(world * W * H / (t_train / K) / 1e6, 2),
             "fwd_fps": round(1e3 / fwd_ms, 2),
+            "profiled_fwd_ms": round(t_fwd_prof / K * 1e3, 3), "profiled_train_ms": round(t_train_prof / K * 1e3, 3),
+            "fwd_step_ms_in_order": [round(v, 3) for v in fwd_order], "train_step_ms_in_order": [round(v, 3) for v in train_order],
             "fwd_step_ms_p10_p50_p90": [pct(fwd_steps, 0.1), pct(fwd_steps, 0.5), pct(fwd_steps, 0.9)],
             "train_step_ms_p10_p50_p90": [pct(train_steps, 0.1), pct(train_steps, 0.5), pct(train_steps, 0.9)],
             "hbm_copy_measured_GBs": copy_GBs,
