@@ -163,12 +163,14 @@ def _round_ws(nbytes: int) -> int:
 
 # ---- deferred count check of the sync-free forward -----------------------------------------------------------------
 class _CapacityState:
-    """Per (device, P, W, H, binning mode): the instance capacity later frames are issued with."""
-    __slots__ = ("capacity", "last_counts")
+    """Per (device, P, W, H, binning mode): the instance capacity later frames are issued with, and the workspaces
+    forward-only frames share (nothing reads them after the frame: a fresh allocation per frame is pure host time)."""
+    __slots__ = ("capacity", "last_counts", "fo_ws")
 
     def __init__(self):
         self.capacity = 0
         self.last_counts = (0, 0)
+        self.fo_ws = {}         # stream handle -> (capacity, geom, img, binning) of the forward-only frames on that stream
 
     def observe(self, R: int, V: int) -> None:
         self.last_counts = (R, V)
@@ -319,19 +321,31 @@ class _Frame(NamedTuple):
 def _run_forward(lib, dev, params, P: int, W: int, H: int):
     """Native forward on torch's current stream.  Returns (color, _Frame)."""
     stream = _stream(dev)
-    geom = torch.empty(lib.gsr_geom_bytes(P), dtype=torch.uint8, device=dev)
-    img = torch.empty(lib.gsr_image_bytes(W, H), dtype=torch.uint8, device=dev)
     radii = torch.empty(P, dtype=torch.int32, device=dev)      # written for every Gaussian by the kernel
     color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
     mode = params.binning_mode
     st = _state_for((dev.index or 0, P, W, H, mode))
     _drain_pending()
-    if _sync_free_value and st.capacity > 0 and mode != _lib.BINNING_KEYS64 and P > 0:
+    sync_free = _sync_free_value and st.capacity > 0 and mode != _lib.BINNING_KEYS64 and P > 0
+    cached = st.fo_ws.get(stream) if (sync_free and params.forward_only) else None
+    if cached is not None and cached[0] == st.capacity:
+        # forward-only frames of one stream run one after the other and nothing outlives them: same workspaces every frame
+        _, geom, img, binning = cached
+    else:
+        geom = torch.empty(lib.gsr_geom_bytes(P), dtype=torch.uint8, device=dev)
+        img = torch.empty(lib.gsr_image_bytes(W, H), dtype=torch.uint8, device=dev)
+        binning = None
+    if sync_free:
         cap = st.capacity
         slot, event = _pinned_slot(), _new_event()
         params.counts_pinned = slot.data_ptr()
         nbytes = lib.gsr_binning_bytes(cap, P, W, H, mode)
-        binning = torch.empty(_round_ws(nbytes), dtype=torch.uint8, device=dev)
+        if binning is None:
+            binning = torch.empty(_round_ws(nbytes), dtype=torch.uint8, device=dev)
+            if params.forward_only:
+                if len(st.fo_ws) > 4:
+                    st.fo_ws.clear()
+                st.fo_ws[stream] = (cap, geom, img, binning)
         pend = _Pending(event, slot, cap, st)
         with _defer_lock:
             _pending.append(pend)
@@ -566,20 +580,37 @@ def _forward_only(*tensors) -> bool:
     return not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors))
 
 
+class _NoGraph:
+    """Stands in for the autograd context when no backward can follow: the operator's forward runs as a plain function
+    (``Function.apply`` and its bookkeeping are ~20 us of host time per frame, a tenth of a 100 k-Gaussian frame)."""
+
+    def save_for_backward(self, *tensors):
+        pass
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+
 def rasterize_gaussians_fused(means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations, raster_settings,
                               densify_stats=None):
     """``densify_stats``: None, or (xyz_gradient_accum, denom, max_radii2D) -- the backward then also accumulates the
     densification statistics of ``scene/gaussian_model.py:775-777`` / ``train.py:130``."""
-    fo = _forward_only(means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations)
+    if _forward_only(means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations):
+        with torch.no_grad():
+            return _RasterizeGaussiansFused.forward(_NoGraph(), means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales,
+                                                    raw_rotations, raster_settings, True, None)
     return _RasterizeGaussiansFused.apply(means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations,
-                                          raster_settings, fo, densify_stats)
+                                          raster_settings, False, densify_stats)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings, densify_stats=None):
-    fo = _forward_only(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
+    if _forward_only(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp):
+        with torch.no_grad():
+            return _RasterizeGaussians.forward(_NoGraph(), means3D, means2D, sh, colors_precomp, opacities, scales,
+                                               rotations, cov3Ds_precomp, raster_settings, True, None)
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, fo, densify_stats)
+                                     cov3Ds_precomp, raster_settings, False, densify_stats)
 
 
 class GaussianRasterizer(nn.Module):

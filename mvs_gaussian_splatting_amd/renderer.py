@@ -9,7 +9,7 @@ import math
 
 import torch
 
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians_fused
 from .sh import eval_sh
 
 
@@ -92,15 +92,16 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier:
         prefiltered=False,
         debug=bool(getattr(pipe, "debug", False)),
     )
-    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
-
     if _can_fuse(pc, pipe, override_color):
-        # same result as the getter path below, without materialising cat(f_dc, f_rest), exp, normalize, sigmoid
-        rendered_image, radii = rasterizer.forward_fused(xyz, screenspace_points, pc._features_dc, pc._features_rest,
-                                                         pc._opacity, pc._scaling, pc._rotation, densify_stats=stats)
+        # same result as the getter path below, without materialising cat(f_dc, f_rest), exp, normalize, sigmoid (and
+        # without building an nn.Module per frame: the operator is called as a function)
+        rendered_image, radii = rasterize_gaussians_fused(xyz, screenspace_points, pc._features_dc, pc._features_rest,
+                                                          pc._opacity, pc._scaling, pc._rotation, raster_settings,
+                                                          densify_stats=stats)
         return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
                 "radii": radii, "selected_pts_mask": None}
 
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
     scales = rotations = cov3D_precomp = None
     if getattr(pipe, "compute_cov3D_python", False):
         cov3D_precomp = pc.get_covariance(scaling_modifier)

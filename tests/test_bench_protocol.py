@@ -90,3 +90,23 @@ def test_single_process_and_explicit_gloo_need_no_agreement():
     assert not p.cpu_collectives and not p.rccl_failed and p.rccl_ranks is None
     p = negotiate_collectives(4, "gloo", boom, boom)
     assert p.cpu_collectives and not p.rccl_failed and p.backend_note == "gloo"
+
+
+def test_byte_models_of_the_roofline_objects():
+    """bench.py prices the per-Gaussian kernels on the bytes a frame has to move (model v2) and keeps SURVEY §8(d)'s
+    model v1 beside it: v2 never exceeds v1 by more than the instance rows, equals v1's shape when everything is visible,
+    and charges a culled Gaussian 44 bytes in the forward."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    P, M, W, H = 6_000_000, 16, 1920, 1080
+    v1 = bench.algorithmic_bytes(P, M, 8_192_108, W, H, 6)
+    assert v1["preprocess_fwd"] == P * (44 + 12 * M + 75) and v1["render_fwd"] == 40 * 8_192_108 + 20 * W * H
+    v2_all = bench.bytes_really_moved(P, M, P, 0, W, H)
+    assert v2_all["preprocess_fwd"] == v1["preprocess_fwd"]                  # everything visible: the same bytes
+    v2 = bench.bytes_really_moved(P, M, 3_880_905, 8_192_108, W, H)
+    assert v2["preprocess_fwd"] == 44 * P + (12 * M + 75) * 3_880_905 < v1["preprocess_fwd"]
+    assert bench.bytes_really_moved(P, M, 0, 0, W, H)["preprocess_fwd"] == 44 * P      # nothing visible: 44 B per Gaussian
+    assert v2["preprocess_bwd"] < v1["preprocess_bwd"] + 49 * 8_192_108
