@@ -66,7 +66,8 @@ class GraphedRenderer:
                 self.inputs = dict(means3D=pc.get_xyz.detach().contiguous(), sh=pc._features_dc.detach().contiguous(),
                                    colors_precomp=empty, opacities=pc._opacity.detach().contiguous(),
                                    scales=pc._scaling.detach().contiguous(), rotations=pc._rotation.detach().contiguous(),
-                                   cov3Ds_precomp=empty, sh_rest=pc._features_rest.detach().contiguous())
+                                   cov3Ds_precomp=empty,
+                                   sh_rest=pc._features_rest.detach().contiguous() if pc._features_rest.shape[1] else None)
                 self.act_flags = _lib.ACT_SCALE_EXP | _lib.ACT_ROT_NORMALIZE | _lib.ACT_OPACITY_SIGMOID
             else:
                 self.fused = False

@@ -507,10 +507,12 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
         raw_opacity = _f32c(raw_opacity, "opacity", dev)
         raw_scales = _f32c(raw_scales, "scaling", dev)
         raw_rotations = _f32c(raw_rotations, "rotation", dev, align16=True)
-        if f_dc.shape[0] != P or f_dc.numel() != 3 * P or f_rest.shape[0] != P or f_rest.shape[1] != 15:
-            raise ValueError("fused inputs need f_dc [P,1,3] and f_rest [P,15,3]")
+        n_rest = int(f_rest.shape[1]) if f_rest.dim() == 3 else -1
+        if f_dc.shape[0] != P or f_dc.numel() != 3 * P or f_rest.shape[0] != P or n_rest not in (0, 15):
+            raise ValueError("fused inputs need f_dc [P,1,3] and f_rest [P,15,3] (degree-3 storage) or [P,0,3] (degree 0)")
         _check_rows(means3D, "means3D", P, 3)
-        _check_rows(f_rest, "f_rest", P, 15, 3)
+        if n_rest:
+            _check_rows(f_rest, "f_rest", P, 15, 3)
         _check_rows(raw_scales, "scaling", P, 3)
         _check_rows(raw_rotations, "rotation", P, 4)
         if raw_opacity.numel() != P or raw_scales.numel() != 3 * P or raw_rotations.numel() != 4 * P:
@@ -519,8 +521,10 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
         empty = torch.empty(0, dtype=torch.float32, device=dev)
         flags = _lib.ACT_SCALE_EXP | _lib.ACT_ROT_NORMALIZE | _lib.ACT_OPACITY_SIGMOID
         with torch.cuda.device(dev):
+            # degree-0 storage: f_dc [P,1,3] is the whole SH tensor (M = 1), there is no rest to split off
             params, keep = _make_params(dev, raster_settings, means3D, f_dc, empty, raw_opacity, raw_scales,
-                                        raw_rotations, empty, sh_rest=f_rest, act_flags=flags, forward_only=forward_only)
+                                        raw_rotations, empty, sh_rest=f_rest if n_rest else None, act_flags=flags,
+                                        forward_only=forward_only)
             try:
                 color, frame = _run_forward(lib, dev, params, P, W, H)
             except _lib.GsrError:
@@ -552,8 +556,9 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
         grad_out_color = _f32c(grad_out_color, "grad_out_color", dev, align16=True)
         empty = torch.empty(0, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
+            has_rest = f_rest.numel() > 0
             params, keep = _make_params(dev, settings, means3D, f_dc, empty, raw_opacity, raw_scales, raw_rotations,
-                                        empty, sh_rest=f_rest, act_flags=ctx.act_flags)
+                                        empty, sh_rest=f_rest if has_rest else None, act_flags=ctx.act_flags)
             params.profile = ctx.profile.handle() if ctx.profile is not None else None
             params.binning_mode = ctx.binning_mode
             new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
@@ -561,7 +566,7 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
             g_dc, g_rest = new(*f_dc.shape), new(*f_rest.shape)
             g_opac, g_scales, g_rot = new(*raw_opacity.shape), new(P, 3), new(P, 4)
             grads = _lib.GsrGrads(_ptr(g_means3D), _ptr(g_means2D), _ptr(g_dc), None, _ptr(g_opac), _ptr(g_scales),
-                                  _ptr(g_rot), None, _ptr(g_rest), *_stats_ptrs(ctx.stats, P, dev))
+                                  _ptr(g_rot), None, _ptr(g_rest) if has_rest else None, *_stats_ptrs(ctx.stats, P, dev))
             frame = _Frame(geom, binning, img, radii, ctx.layout[0], ctx.layout[1], ctx.frame_pending)
             try:
                 _run_backward(lib, dev, params, frame, grad_out_color, grads)

@@ -28,7 +28,8 @@ def _can_fuse(pc, pipe, override_color) -> bool:
             getattr(pc, "rotation_activation", None) is not torch.nn.functional.normalize:
         return False
     fr = pc._features_rest
-    return fr.dim() == 3 and fr.shape[1] == 15 and pc._features_dc.shape[1] == 1 and pc._xyz.is_cuda
+    # degree-3 storage (15 rest coefficients: split SH rows) or degree-0 storage (none: f_dc IS the SH tensor)
+    return fr.dim() == 3 and fr.shape[1] in (0, 15) and pc._features_dc.shape[1] == 1 and pc._xyz.is_cuda
 
 
 _ZEROS = {}

@@ -169,16 +169,18 @@ def test_backward_matches_fp64_oracle(gpu_device, deg, use_cov, colors):
                         use_cov, use_colors)
 
 
-def test_fused_raw_parameter_path_matches_unfused_and_oracle(gpu_device):
-    """render() fed with raw parameters (split SH, activations inside the kernels) must give the
-    pixels and raw-parameter gradients of the getter path / the fp64 oracle."""
+@pytest.mark.parametrize("deg", [3, 0])
+def test_fused_raw_parameter_path_matches_unfused_and_oracle(gpu_device, deg):
+    """SURVEY §8 f2: render() fed with raw parameters (split SH for degree-3 storage, f_dc alone for degree-0 storage;
+    activations inside the kernels) must give the pixels and raw-parameter gradients of the getter path / the fp64 oracle."""
     from mvs_gaussian_splatting_amd import render
     from mvs_gaussian_splatting_amd.synthetic import PipelineParams
     from grad_util import grads_oracle, compare_grads, masked_l1
     dev = gpu_device
-    model, cam, _, target = small_scene(P=2500, sh_degree=3, width=208, height=120, scale=0.06)
+    from mvs_gaussian_splatting_amd.renderer import _can_fuse
+    model, cam, _, target = small_scene(P=2500, sh_degree=deg, width=208, height=120, scale=0.06)
     bg = torch.tensor([0.3, 0.1, 0.2])
-    st_o = make_settings(cam, bg, 3)
+    st_o = make_settings(cam, bg, deg)
     ref, weight, aux, _ = grads_oracle(model, st_o, target)
     ref32, _, _, _ = grads_oracle(model, st_o, target, dtype=torch.float32, weight=weight)
     model.to(dev); cam.to(dev)
@@ -189,11 +191,14 @@ def test_fused_raw_parameter_path_matches_unfused_and_oracle(gpu_device):
             p.requires_grad_(True)
         pipe = PipelineParams()
         pipe.fuse_activations = fused
+        assert _can_fuse(model, pipe, None) == fused
         pkg = render(cam, model, pipe, bg.to(dev))
         masked_l1(pkg["render"], target, weight).backward()
         out[fused] = (pkg["render"].detach().cpu(), pkg["radii"].cpu(),
                       {"xyz": model._xyz.grad.cpu(), "f_dc": model._features_dc.grad.cpu(),
-                       "f_rest": model._features_rest.grad.cpu(), "opacity": model._opacity.grad.cpu(),
+                       "f_rest": (model._features_rest.grad.cpu() if model._features_rest.grad is not None
+                                  else torch.zeros_like(model._features_rest).cpu()),
+                       "opacity": model._opacity.grad.cpu(),
                        "scaling": model._scaling.grad.cpu(), "rotation": model._rotation.grad.cpu(),
                        "means2D": pkg["viewspace_points"].grad.cpu()})
     assert int((out[True][1] != out[False][1]).sum()) <= 2          # expf vs torch.exp may flip a ceil()
