@@ -347,10 +347,17 @@ def _run_forward(lib, dev, params, P: int, W: int, H: int):
                     st.fo_ws.clear()
                 st.fo_ws[stream] = (cap, geom, img, binning)
         pend = _Pending(event, slot, cap, st)
+        slot[0] = 0                 # a frame whose enqueue fails half-way must not be read as an overflow later
+        try:
+            _lib.check(lib.gsr_forward(C.byref(params), geom.data_ptr(), binning.data_ptr(), nbytes, cap, img.data_ptr(),
+                                       radii.data_ptr(), color.data_ptr(), event, stream), "gsr_forward")
+        except _lib.GsrError:
+            with _defer_lock:       # nothing of this frame is pending: give the slot and the event back
+                _free_slots.append(slot)
+                _free_events.append(event)
+            raise
         with _defer_lock:
             _pending.append(pend)
-        _lib.check(lib.gsr_forward(C.byref(params), geom.data_ptr(), binning.data_ptr(), nbytes, cap, img.data_ptr(),
-                                   radii.data_ptr(), color.data_ptr(), event, stream), "gsr_forward")
         return color, _Frame(geom, binning, img, radii, cap, P, pend)
     pinned = _counts_pinned_two_call()
     params.counts_pinned = pinned.data_ptr()

@@ -10,7 +10,20 @@ from scene_gpu import GpuScene
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 cfg = args[0] if len(args) > 0 else "C4"
 iters = int(args[1]) if len(args) > 1 else 10
-s = GpuScene(cfg, fused="--fused" in sys.argv)       # --fused: raw parameters + split SH, as render() feeds them
+def wide_depth(model):
+    """--wide-depth: the same screen positions and footprints with the depths spread over 23 binades (0.25 .. 2e6): every
+    frame then needs the depth sort's fourth pass (the bench cloud's z in 3..9 never takes it)."""
+    import math
+    g = torch.Generator().manual_seed(11)
+    P = model._xyz.shape[0]
+    z = torch.exp(torch.rand(P, generator=g) * (math.log(2.0e6) - math.log(0.25)) + math.log(0.25))
+    s_ = z / model._xyz[:, 2]
+    model._xyz *= s_[:, None]
+    model._scaling += torch.log(s_)[:, None]
+
+
+s = GpuScene(cfg, fused="--fused" in sys.argv,       # --fused: raw parameters + split SH, as render() feeds them
+             mutate=wide_depth if "--wide-depth" in sys.argv else None)
 s.fuse_stats = "--stats" in sys.argv                 # --stats: the backward also takes the densification statistics
 dL = torch.sign(torch.rand(3, s.H, s.W, device=s.dev) - 0.5) / (3 * s.H * s.W)
 for _ in range(2):
