@@ -168,3 +168,20 @@ def test_markers_switch(gpu_device, fresh_state):
         assert torch.isfinite(pkg["render"]).all()
     finally:
         _lib.enable_markers(False)
+
+
+def test_full_size_C3_frame_without_readback_equals_the_two_call_frame(gpu_device):
+    """BASELINE config 3 (1 M Gaussians, 1080p) through the raw C ABI: gsr_forward at 1.5 x capacity leaves the same image,
+    per-pixel state, lists and ranges as the two-call forward -- the size-independent property the small scenes above
+    check, at a size where every launch is really sized for a capacity beyond the count (blocks past the count exit)."""
+    from gpu_util import forward_with_state, product_settings
+    from mvs_gaussian_splatting_amd.synthetic import CONFIGS, make_scene
+    model, cam, bg, _ = make_scene(CONFIGS["C3"])
+    st = product_settings(cam, bg, 3, gpu_device)
+    kw = dict(shs=model.get_features, scales=model.get_scaling, rotations=model.get_rotation, binning_mode=2)
+    ref = forward_with_state(gpu_device, st, model.get_xyz, model.get_opacity, **kw)
+    out = forward_with_state(gpu_device, st, model.get_xyz, model.get_opacity, sync_free_capacity=int(1.5 * ref["R"]), **kw)
+    assert (out["R"], out["V"]) == (ref["R"], ref["V"]) and ref["R"] > 2_000_000
+    for k in ("color", "final_T", "n_contrib", "radii"):
+        assert torch.equal(out[k], ref[k]), k
+    assert np.array_equal(out["point_list"], ref["point_list"]) and np.array_equal(out["ranges"], ref["ranges"])
