@@ -575,35 +575,52 @@ __global__ __launch_bounds__(1024) void build_tile_order_kernel(int tiles, const
   const unsigned long long lt = (1ull << lane) - 1ull;
   if (tid < 256) cnt[tid] = 0;
   __syncthreads();
-  for (int t0 = 0; t0 < tiles; t0 += 1024) {
-    const int t = t0 + tid;
-    const bool ok = t < tiles;
-    uint32_t code = 0;
-    if (ok) { const uint2 r = ranges[t]; code = 255u - len_bucket(r.y - r.x); }
-    const unsigned long long peers = match8(code, ok);
-    if (ok && (peers & lt) == 0ull) atomicAdd(&cnt[code], (uint32_t)__popcll(peers));     // one atomic per group
-  }
-  __syncthreads();
-  if (tid < WAVE) {     // exclusive scan of the 256 counts by one wave (4 per lane)
-    uint32_t c[4], mine = 0;
+  // Chunks of 8 x 1024 tiles: a thread's eight ranges are requested together (one trip to memory instead of eight) and
+  // their codes stay in registers for the second pass (round 2 re-read every range: 16 dependent round-trips, 14 us for
+  // the 8160 tiles of a 1080p frame on the critical path of every forward).
+  constexpr int PER = 8;
+  for (int c0 = 0; c0 < tiles; c0 += PER * 1024) {
+    uint32_t code[PER];
+    uint2 r[PER];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { c[k] = cnt[4 * tid + k]; mine += c[k]; }
-    uint32_t run = wave_incl_scan_u32(mine) - mine;
+    for (int u = 0; u < PER; ++u) {
+      const int t = c0 + u * 1024 + tid;
+      r[u] = t < tiles ? ranges[t] : make_uint2(0u, 0u);
+    }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { base[4 * tid + k] = run; run += c[k]; }
-  }
-  __syncthreads();
-  for (int t0 = 0; t0 < tiles; t0 += 1024) {
-    const int t = t0 + tid;
-    const bool ok = t < tiles;
-    uint32_t code = 0;
-    if (ok) { const uint2 r = ranges[t]; code = 255u - len_bucket(r.y - r.x); }
-    const unsigned long long peers = match8(code, ok);
-    uint32_t first = 0;
-    const int leader = __ffsll((long long)peers) - 1;
-    if (ok && lane == leader) first = atomicAdd(&base[code], (uint32_t)__popcll(peers));
-    first = (uint32_t)__shfl((int)first, leader, WAVE);
-    if (ok) order[first + (uint32_t)__popcll(peers & lt)] = (uint32_t)t;
+    for (int u = 0; u < PER; ++u) code[u] = 255u - len_bucket(r[u].y - r[u].x);
+    if (c0 > 0) __syncthreads();          // the previous chunk's second pass is done with cnt / base
+    if (c0 > 0 && tid < 256) cnt[tid] = 0;
+    if (c0 > 0) __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const bool ok = c0 + u * 1024 + tid < tiles;
+      const unsigned long long peers = match8(code[u], ok);
+      if (ok && (peers & lt) == 0ull) atomicAdd(&cnt[code[u]], (uint32_t)__popcll(peers));     // one atomic per group
+    }
+    __syncthreads();
+    if (tid < WAVE) {     // exclusive scan of the 256 counts by one wave (4 per lane)
+      uint32_t c[4], mine = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { c[k] = cnt[4 * tid + k]; mine += c[k]; }
+      uint32_t run = wave_incl_scan_u32(mine) - mine;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { base[4 * tid + k] = run; run += c[k]; }
+    }
+    __syncthreads();
+    // a frame of more than 8192 tiles is ordered chunk by chunk (longest first inside each chunk): the order only
+    // balances the tail of the compositing kernels, no result depends on it
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int t = c0 + u * 1024 + tid;
+      const bool ok = t < tiles;
+      const unsigned long long peers = match8(code[u], ok);
+      uint32_t first = 0;
+      const int leader = __ffsll((long long)peers) - 1;
+      if (ok && lane == leader) first = atomicAdd(&base[code[u]], (uint32_t)__popcll(peers));
+      first = (uint32_t)__shfl((int)first, leader, WAVE);
+      if (ok) order[c0 + first + (uint32_t)__popcll(peers & lt)] = (uint32_t)t;
+    }
   }
 }
 

@@ -780,3 +780,35 @@ def test_packed_rect_payload_boundaries(gpu_device):
     assert set(zip((o[2]["keys"] >> np.uint64(32)).tolist(), o[2]["point_list"].tolist())) <= full
     assert np.all(o[2]["keys"][1:] >= o[2]["keys"][:-1])
     assert torch.equal(o[2]["color"], o[0]["color"])
+
+
+def test_frame_of_more_than_8192_tiles(gpu_device):
+    """build_tile_order handles the tiles in chunks of 8192 (one trip to memory per chunk): a frame with more tiles than
+    that (2112 x 1104 -> 132 x 69 = 9108) must still composite every tile exactly once -- checked against the oracle on
+    every 5th tile and on all tiles of the second chunk."""
+    from gpu_util import forward_with_state, product_settings
+    from mvs_gaussian_splatting_amd.synthetic import SceneConfig, make_scene
+    from oracle import rasterize_ref
+    W, H = 2112, 1104
+    cfg = SceneConfig("big", 3000, 1, W, H, 1300.0, 1300.0, math.log(0.05))
+    model, cam, _, _ = make_scene(cfg, seed=4)
+    bg = torch.tensor([0.2, 0.5, 0.1])
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    assert gx * gy > 8192
+    tiles = sorted(set(range(0, gx * gy, 5)) | set(range(8192, gx * gy)))
+    st_o = make_settings(cam, bg, 1)
+    col, radii, aux = rasterize_ref(model.get_xyz, None, model.get_opacity, st_o, shs=model.get_features,
+                                    scales=model.get_scaling, rotations=model.get_rotation, want_aux=True, want_margin=True,
+                                    tiles=tiles)
+    out = forward_with_state(gpu_device, product_settings(cam, bg, 1, gpu_device), model.get_xyz, model.get_opacity,
+                             shs=model.get_features, scales=model.get_scaling, rotations=model.get_rotation, binning_mode=2)
+    assert torch.equal(out["radii"], radii)
+    mask = torch.zeros(gy * 16, gx * 16, dtype=torch.bool)
+    for t in tiles:
+        ty, tx = divmod(t, gx)
+        mask[ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16] = True
+    mask = mask[:H, :W] & (aux["margin"] > 1e-4)
+    err = ((out["color"] - col).abs() / col.abs().clamp(min=1.0)).max(dim=0).values
+    assert int(mask.sum()) > 100_000 and float(err[mask].max()) <= 1e-5
+    touched = (out["n_contrib"] > 0)
+    assert int(touched[:, : W // 2].sum()) > 0 and int(touched[H - 64:, :].sum()) > 0      # the last tile rows are composited too
