@@ -222,10 +222,6 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
   __shared__ uint32_t wave_sums[PRE_BLOCK / WAVE];
   __shared__ uint32_t wave_vis[PRE_BLOCK / WAVE];
   __shared__ uint2 wave_range[PRE_BLOCK / WAVE];
-#ifdef PRE_FWD_DUMMY_LDS      // occupancy experiment: how much does preprocess_fwd lose at 3 / 2 waves per SIMD?
-  __shared__ char occupancy_dummy[PRE_FWD_DUMMY_LDS];
-  if (p.P < 0) occupancy_dummy[threadIdx.x] = 1;
-#endif
   const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
   const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
   const int W = p.width, H = p.height;

@@ -720,10 +720,6 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE, BWD_WAVES) void render_bwd_
                                                           GradRow* __restrict__ rows,
                                                           uint8_t* __restrict__ row_flags) {
   __shared__ SbLds sL[WAVES_PER_BLOCK];
-#ifdef GSR_BWD_DUMMY_LDS      // occupancy experiment (tools/build_variant.sh): blocks per CU limited through LDS
-  __shared__ char occupancy_dummy[GSR_BWD_DUMMY_LDS];
-  if (W < 0) occupancy_dummy[threadIdx.x] = 1;
-#endif
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
   const int slot = blockIdx.x * WAVES_PER_BLOCK + wid;
   if (slot >= num_tiles) return;
