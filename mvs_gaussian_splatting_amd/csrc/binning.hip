@@ -569,34 +569,35 @@ __device__ inline unsigned long long match8(uint32_t code, bool ok) {
 }
 __global__ __launch_bounds__(1024) void build_tile_order_kernel(int tiles, const uint2* __restrict__ ranges,
                                                                 uint32_t* __restrict__ order) {
+  constexpr int CHUNK = 8 * 1024;       // tiles ordered per pass (a 1080p frame has 8160)
   __shared__ uint32_t cnt[256];
   __shared__ uint32_t base[256];
+  __shared__ uint8_t s_code[CHUNK];     // the length code of every tile of the chunk: the ranges are read ONCE
   const int tid = threadIdx.x, lane = tid & (WAVE - 1);
   const unsigned long long lt = (1ull << lane) - 1ull;
-  if (tid < 256) cnt[tid] = 0;
-  __syncthreads();
-  // Chunks of 8 x 1024 tiles: a thread's eight ranges are requested together (one trip to memory instead of eight) and
-  // their codes stay in registers for the second pass (round 2 re-read every range: 16 dependent round-trips, 14 us for
-  // the 8160 tiles of a 1080p frame on the critical path of every forward).
-  constexpr int PER = 8;
-  for (int c0 = 0; c0 < tiles; c0 += PER * 1024) {
-    uint32_t code[PER];
-    uint2 r[PER];
+  for (int c0 = 0; c0 < tiles; c0 += CHUNK) {
+    if (c0 > 0) __syncthreads();        // the previous chunk's second pass is done with cnt / base / s_code
+    if (tid < 256) cnt[tid] = 0;
+    // one trip to memory for the whole chunk: eight independent loads per thread in flight (round 2 read every range
+    // twice, in sixteen dependent trips: 14 us for the 8160 tiles of a 1080p frame, on the critical path of every forward)
+    {
+      uint2 r[8];
 #pragma unroll
-    for (int u = 0; u < PER; ++u) {
-      const int t = c0 + u * 1024 + tid;
-      r[u] = t < tiles ? ranges[t] : make_uint2(0u, 0u);
+      for (int u = 0; u < 8; ++u) {
+        const int t = c0 + u * 1024 + tid;
+        r[u] = t < tiles ? ranges[t] : make_uint2(0u, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s_code[u * 1024 + tid] = (uint8_t)(255u - len_bucket(r[u].y - r[u].x));
     }
-#pragma unroll
-    for (int u = 0; u < PER; ++u) code[u] = 255u - len_bucket(r[u].y - r[u].x);
-    if (c0 > 0) __syncthreads();          // the previous chunk's second pass is done with cnt / base
-    if (c0 > 0 && tid < 256) cnt[tid] = 0;
-    if (c0 > 0) __syncthreads();
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-      const bool ok = c0 + u * 1024 + tid < tiles;
-      const unsigned long long peers = match8(code[u], ok);
-      if (ok && (peers & lt) == 0ull) atomicAdd(&cnt[code[u]], (uint32_t)__popcll(peers));     // one atomic per group
+    __syncthreads();
+    const int n = min(CHUNK, tiles - c0);
+    for (int t0 = 0; t0 < n; t0 += 1024) {
+      const int t = t0 + tid;
+      const bool ok = t < n;
+      const uint32_t code = s_code[t0 + tid];
+      const unsigned long long peers = match8(code, ok);
+      if (ok && (peers & lt) == 0ull) atomicAdd(&cnt[code], (uint32_t)__popcll(peers));     // one atomic per group
     }
     __syncthreads();
     if (tid < WAVE) {     // exclusive scan of the 256 counts by one wave (4 per lane)
@@ -610,16 +611,16 @@ __global__ __launch_bounds__(1024) void build_tile_order_kernel(int tiles, const
     __syncthreads();
     // a frame of more than 8192 tiles is ordered chunk by chunk (longest first inside each chunk): the order only
     // balances the tail of the compositing kernels, no result depends on it
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-      const int t = c0 + u * 1024 + tid;
-      const bool ok = t < tiles;
-      const unsigned long long peers = match8(code[u], ok);
+    for (int t0 = 0; t0 < n; t0 += 1024) {
+      const int t = t0 + tid;
+      const bool ok = t < n;
+      const uint32_t code = s_code[t0 + tid];
+      const unsigned long long peers = match8(code, ok);
       uint32_t first = 0;
       const int leader = __ffsll((long long)peers) - 1;
-      if (ok && lane == leader) first = atomicAdd(&base[code[u]], (uint32_t)__popcll(peers));
+      if (ok && lane == leader) first = atomicAdd(&base[code], (uint32_t)__popcll(peers));
       first = (uint32_t)__shfl((int)first, leader, WAVE);
-      if (ok) order[c0 + first + (uint32_t)__popcll(peers & lt)] = (uint32_t)t;
+      if (ok) order[c0 + first + (uint32_t)__popcll(peers & lt)] = (uint32_t)(c0 + t);
     }
   }
 }
