@@ -164,19 +164,25 @@ struct SortedViews {
   const uint32_t* point_list;
   const uint32_t* tile_sorted;   // mode 0
   const uint64_t* keys_sorted;   // mode 1
+  // the sort's other payload buffer, free once the sort is done: render_fwd leaves the mini-block reach mask of every
+  // instance (list order, 2 bytes each) there for render_bwd
+  uint16_t* inst_mask;
 };
 SortedViews sorted_views(const void* bin_ws, uint32_t R, uint32_t V, int W, int H, int mode) {
   const ImageLayout I(W, H);
   const BinLayout B(R, V, mode);
-  SortedViews v{nullptr, nullptr, nullptr};
+  SortedViews v{nullptr, nullptr, nullptr, nullptr};
+  char* ws = const_cast<char*>(static_cast<const char*>(bin_ws));
   if (mode == GSR_BINNING_KEYS64) {
     const bool in_b = (sort_passes(32 + tile_bits(I.tiles)) & 1) != 0;
     v.point_list = at<uint32_t>(bin_ws, in_b ? B.vals_b : B.vals_a);
     v.keys_sorted = at<uint64_t>(bin_ws, in_b ? B.keys_b : B.keys_a);
+    v.inst_mask = reinterpret_cast<uint16_t*>(ws + (in_b ? B.vals_a : B.vals_b));
   } else {
     const bool in_b = (sort_passes(tile_bits(I.tiles)) & 1) != 0;
     v.point_list = at<uint32_t>(bin_ws, in_b ? B.ig_b : B.ig_a);
     v.tile_sorted = at<uint32_t>(bin_ws, in_b ? B.itile_b : B.itile_a);
+    v.inst_mask = reinterpret_cast<uint16_t*>(ws + (in_b ? B.ig_a : B.ig_b));
   }
   return v;
 }
@@ -258,6 +264,7 @@ static int enqueue_stage2(const GsrParams* p, void* geom_ws, void* bin_ws, size_
   uint2* ranges = at<uint2>(img_ws, I.ranges);
   GSR_HIP(hipMemsetAsync(ranges, 0, 8 * (size_t)I.tiles, s));
   const uint32_t* point_list = nullptr;
+  uint16_t* inst_mask = nullptr;     // the sort's spare payload buffer (see SortedViews)
   const GeomRec* rec = nullptr;
   if (p->P > 0 && r_cap > 0) {
     if (!geom_ws || !bin_ws) return fail(GSR_E_BADARG, "geom_ws / bin_ws is NULL");
@@ -295,6 +302,7 @@ static int enqueue_stage2(const GsrParams* p, void* geom_ws, void* bin_ws, size_
         launch_identify_tile_ranges(r_cap, in_b ? kb : ka, ranges, s);
       }
       point_list = in_b ? vb : va;
+      inst_mask = reinterpret_cast<uint16_t*>(in_b ? va : vb);
     } else {
       uint32_t* ita = at<uint32_t>(bin_ws, B.itile_a);
       uint32_t* itb = at<uint32_t>(bin_ws, B.itile_b);
@@ -326,6 +334,7 @@ static int enqueue_stage2(const GsrParams* p, void* geom_ws, void* bin_ws, size_
         launch_identify_tile_ranges_u32(r_cap, in_b ? itb : ita, ranges, s, r_dev);
       }
       point_list = in_b ? igb : iga;
+      inst_mask = reinterpret_cast<uint16_t*>(in_b ? iga : igb);
     }
     if (int rc = check(p, s, "identify_tile_ranges")) return rc;
   }
@@ -336,7 +345,7 @@ static int enqueue_stage2(const GsrParams* p, void* geom_ws, void* bin_ws, size_
     launch_render_fwd(p->width, p->height, ranges, point_list, rec, p->bg, out_color,
                       track ? at<float>(img_ws, I.final_T) : nullptr, track ? at<uint32_t>(img_ws, I.n_contrib) : nullptr,
                       track ? at<uint32_t>(img_ws, I.tile_max) : nullptr, at<uint32_t>(img_ws, I.tile_order), s, nullptr,
-                      (p->debug_flags & GSR_DEBUG_NO_MINIBLOCK_CULL) ? 0 : 1);
+                      (p->debug_flags & GSR_DEBUG_NO_MINIBLOCK_CULL) ? 0 : 1, track ? inst_mask : nullptr);
   }
   return check(p, s, "render_fwd");
 }
@@ -491,7 +500,8 @@ int gsr_backward(const GsrParams* p, const int32_t* radii, const void* geom_ws, 
   const GeomRec* rec = at<GeomRec>(geom_ws, L.rec);
   if (R > 0) {
     if (!bin_ws) return fail(GSR_E_BADARG, "bin_ws is NULL");
-    const uint32_t* point_list = sorted_views(bin_ws, R, V, p->width, p->height, p->binning_mode).point_list;
+    const SortedViews sv = sorted_views(bin_ws, R, V, p->width, p->height, p->binning_mode);
+    const uint32_t* point_list = sv.point_list;
     GSR_HIP(hipMemsetAsync(flags, 0, R, s));
     {
       StageTimer t(p, GSR_STAGE_RENDER_BWD, s);
@@ -499,7 +509,7 @@ int gsr_backward(const GsrParams* p, const int32_t* radii, const void* geom_ws, 
                         at<uint32_t>(geom_ws, L.slot_base), p->bg,
                         at<float>(img_ws, I.final_T), at<uint32_t>(img_ws, I.n_contrib),
                         at<uint32_t>(img_ws, I.tile_max), dL_dout_color, rows, flags,
-                        at<uint32_t>(img_ws, I.tile_order), s);
+                        at<uint32_t>(img_ws, I.tile_order), s, sv.inst_mask);
     }
     if (int rc = check(p, s, "render_bwd")) return rc;
   }
@@ -563,12 +573,12 @@ int gsr_debug_render_stats(const GsrParams* p, const void* geom_ws, const void* 
   hipStream_t s = static_cast<hipStream_t>(stream);
   const ImageLayout I(p->width, p->height);
   const GeomLayout L(p->P);
-  launch_render_fwd(p->width, p->height, at<uint2>(img_ws, I.ranges),
-                    sorted_views(bin_ws, R, V, p->width, p->height, p->binning_mode).point_list,
+  const SortedViews sv = sorted_views(bin_ws, R, V, p->width, p->height, p->binning_mode);
+  launch_render_fwd(p->width, p->height, at<uint2>(img_ws, I.ranges), sv.point_list,
                     at<GeomRec>(geom_ws, L.rec), p->bg, out_color, at<float>(img_ws, I.final_T),
                     at<uint32_t>(img_ws, I.n_contrib), at<uint32_t>(img_ws, I.tile_max),
                     at<uint32_t>(img_ws, I.tile_order), s, stats,
-                    (p->debug_flags & GSR_DEBUG_NO_MINIBLOCK_CULL) ? 0 : 1);
+                    (p->debug_flags & GSR_DEBUG_NO_MINIBLOCK_CULL) ? 0 : 1, sv.inst_mask);
   return check(p, s, "render_stats");
 }
 

@@ -62,12 +62,12 @@ void launch_reconstruct_keys(uint32_t R, uint32_t P, const uint32_t* tile_sorted
 // render.hip
 void launch_render_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
                        const float* bg, float* out_color, float* final_T, uint32_t* n_contrib, uint32_t* tile_max,
-                       const uint32_t* tile_order, hipStream_t s, unsigned long long* stats = nullptr, int cull = 1);
+                       const uint32_t* tile_order, hipStream_t s, unsigned long long* stats, int cull, uint16_t* inst_mask);
 void launch_render_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
                        const uint32_t* slot_base,
                        const float* bg, const float* final_T, const uint32_t* n_contrib, const uint32_t* tile_max,
                        const float* dL_dpix, GradRow* rows, uint8_t* row_flags, const uint32_t* tile_order,
-                       hipStream_t s);
+                       hipStream_t s, const uint16_t* inst_mask);
 
 // loss.hip
 void launch_l1_dssim(const float* x, const float* gt, int C, int H, int W, float lambda, int dssim_mode, float* sums,

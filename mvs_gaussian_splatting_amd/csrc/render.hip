@@ -13,9 +13,10 @@
 // different (instance, mini-block) pairs.  A 7x7-pixel footprint costs ~7 groups of 16 lanes instead of ~3.5 sub-blocks
 // of 64.  Skipped pairs would have been rejected pixel by pixel by the alpha test, so results are unchanged.
 //
-// BACKWARD: one wave per tile; every 16-lane group (a DPP row) owns one 8x8 sub-block (a 2x2 pixel quad per lane) and
-// walks its own list of the round's instances that reach it.  The nine per-instance gradient sums are folded over the
-// row with DPP, added to a per-wave LDS slab and written as one row per (Gaussian, tile) instance -- no atomics;
+// BACKWARD: one wave per tile; every 4-lane DPP bank owns one 4x4 mini-block (a 2x2 pixel quad per lane) and walks its own
+// list of the round's instances that reach it -- the reach masks are the forward's, handed over in list order.  The nine
+// per-pair gradient sums are folded over the bank with DPP into an LDS slot per (list, position); the staging lane of an
+// instance sums its slots in mini-block order and writes one row per (Gaussian, tile) instance -- no atomics;
 // preprocess_bwd sums the rows.
 #include "gsr_common.h"
 #include "gsr_launch.h"
@@ -34,57 +35,24 @@ struct Staged {
   uint32_t rect_min, rect_wh, slot_base;
 };
 
-// FULL = false (forward) skips the words the forward never reads -- 4 (cyy) and 11 (tile_mask): a dead destination
-// register of an in-flight load gets recycled by the compiler and forces an early s_waitcnt vmcnt right behind the
-// prefetch, which exposes the whole gather latency.
-template <bool FULL>
+// The forward's staging loads skip the words it never reads -- 3 (cxy: kk replaces it), 4 (cyy) and 11 (tile_mask): a dead
+// destination register of an in-flight load gets recycled by the compiler and forces an early s_waitcnt vmcnt right
+// behind the prefetch, which exposes the whole gather latency.  (The backward has its own loader for the same reason.)
 __device__ inline void load_staged(const GeomRec* __restrict__ rec, uint32_t id, Staged& s) {
-  const float4* r = reinterpret_cast<const float4*>(rec + id);
-  if (FULL) {
-    s.q0 = r[0];
-    s.q1 = r[1];
-    s.q2 = r[2];
-  } else {
-    const float* f = reinterpret_cast<const float*>(r + 1);
-    const float* f0 = reinterpret_cast<const float*>(r);
-    s.q0.x = f0[0];      // word 3 (cxy) is not read either: kk replaces it
-    s.q0.y = f0[1];
-    s.q0.z = f0[2];
-    s.q1.y = f[1];
-    s.q1.z = f[2];
-    s.q1.w = f[3];
-    s.q2.x = f[4];
-    s.q2.y = f[5];
-    s.q2.z = f[6];
-  }
+  const float* f0 = reinterpret_cast<const float*>(rec + id);
+  const float* f = f0 + 4;
+  s.q0.x = f0[0];
+  s.q0.y = f0[1];
+  s.q0.z = f0[2];
+  s.q1.y = f[1];
+  s.q1.z = f[2];
+  s.q1.w = f[3];
+  s.q2.x = f[4];
+  s.q2.y = f[5];
+  s.q2.z = f[6];
   const float2 k = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(rec + id) + 56);
   s.kk = k.x;
   s.isyy = k.y;
-}
-
-// Which of the tile's four 8x8 sub-blocks can the Gaussian reach with alpha >= 1/255 (bit k = sub-block k).
-// Two conservative tests: the bounding box of the alpha >= 1/255 ellipse (GeomRec.ext_x / ext_y), then the exact
-// ellipse-vs-rectangle test q_min <= 2 ln(255 opacity) with a relative + absolute safety margin.  A skipped
-// sub-block would have been rejected pixel by pixel by the alpha test, so results do not change.
-__device__ inline uint32_t subblock_mask(float gx, float gy, float ex, float ey, float cxx, float cxy, float cyy,
-                                         float opacity, float tx0, float ty0) {
-  if (ex < 0.0f) return 0u;
-  const bool xl = (gx + ex >= tx0) && (gx - ex <= tx0 + 7.0f);
-  const bool xr = (gx + ex >= tx0 + 8.0f) && (gx - ex <= tx0 + 15.0f);
-  const bool yt = (gy + ey >= ty0) && (gy - ey <= ty0 + 7.0f);
-  const bool yb = (gy + ey >= ty0 + 8.0f) && (gy - ey <= ty0 + 15.0f);
-  uint32_t m = (uint32_t)(xl && yt) | ((uint32_t)(xr && yt) << 1) | ((uint32_t)(xl && yb) << 2) |
-               ((uint32_t)(xr && yb) << 3);
-  if (m == 0u) return 0u;
-  const float t = 2.0f * 0.6931472f * __log2f(255.0f * opacity) * 1.001f + 2e-3f;
-  const float icxx = __builtin_amdgcn_rcpf(cxx), icyy = __builtin_amdgcn_rcpf(cyy);
-  const float ax0 = tx0 - gx, ay0 = ty0 - gy;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float dx0 = ax0 + 8.0f * (float)(k & 1), dy0 = ay0 + 8.0f * (float)(k >> 1);
-    if (qmin_rect(cxx, cxy, cyy, icxx, icyy, dx0, dx0 + 7.0f, dy0, dy0 + 7.0f) > t) m &= ~(1u << k);
-  }
-  return m;
 }
 
 // LDS image of a staged instance.  The quadratic form is kept as a completed square, pre-scaled by log2(e) so that
@@ -247,6 +215,7 @@ __global__ __launch_bounds__(256, TRACK ? 7 : 8) void render_fwd_kernel(int W, i
                                                          float* __restrict__ final_T,
                                                          uint32_t* __restrict__ n_contrib,
                                                          uint32_t* __restrict__ tile_max,
+                                                         uint16_t* __restrict__ inst_mask,
                                                          unsigned long long* __restrict__ stats) {
   __shared__ float4 sA[QROUND + 1];
   __shared__ float4 sB[QROUND + 1];
@@ -289,7 +258,7 @@ __global__ __launch_bounds__(256, TRACK ? 7 : 8) void render_fwd_kernel(int W, i
   st.kk = st.isyy = 0.0f;
   uint32_t id_next = 0;
   if (len) {
-    load_staged<false>(rec, point_list[start + min((uint32_t)tid, len - 1)], st);
+    load_staged(rec, point_list[start + min((uint32_t)tid, len - 1)], st);
     id_next = point_list[start + min((uint32_t)(QROUND + tid), len - 1)];
   }
   for (uint32_t base = 0; base < len; base += QROUND) {
@@ -307,6 +276,8 @@ __global__ __launch_bounds__(256, TRACK ? 7 : 8) void render_fwd_kernel(int W, i
     sC[tid] = st.q2.x;
     uint32_t m16 = have ? miniblock_mask(st.q0.x - tx0, st.q0.y - ty0, st.q0.z, st.kk, st.isyy, st.q2.y, st.q2.z) : 0u;
     if (!cull_miniblocks) m16 = have ? 0xffffu : 0u;      // debug (GSR_DEBUG_NO_MINIBLOCK_CULL): every pair is evaluated
+    // the backward walks the same (instance, mini-block) pairs: it reads the masks instead of computing them again
+    if (TRACK && have) inst_mask[start + base + tid] = (uint16_t)m16;
     // ---- (b) wave-level ranks: four packed registers of four 8-bit counters --------------------------------------
     uint32_t own[4], incl[4];
 #pragma unroll
@@ -350,7 +321,7 @@ __global__ __launch_bounds__(256, TRACK ? 7 : 8) void render_fwd_kernel(int W, i
     const uint32_t nmax = max(max((uint32_t)__builtin_amdgcn_readlane((int)n_lane, 0), (uint32_t)__builtin_amdgcn_readlane((int)n_lane, 16)),
                               max((uint32_t)__builtin_amdgcn_readlane((int)n_lane, 32), (uint32_t)__builtin_amdgcn_readlane((int)n_lane, 48)));
     // gathers of the next round (clamped indices: lanes past the end re-read the last instance and are masked by `have`)
-    load_staged<false>(rec, id_next, st);
+    load_staged(rec, id_next, st);
     id_next = point_list[start + min(base + 2u * QROUND + (uint32_t)tid, len - 1)];
     __syncthreads();
     // ---- (d) every 16-lane group walks its own list --------------------------------------------------------------
@@ -400,79 +371,77 @@ __global__ __launch_bounds__(256, TRACK ? 7 : 8) void render_fwd_kernel(int W, i
   }
 }
 
-// ---- wave-wide sums ---------------------------------------------------------------------------
-template <int CTRL>
-__device__ inline float dpp_add(float v) {
-  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
-  return v + __int_as_float(moved);
-}
+constexpr int MB_DUMMY = WAVE;                 // LDS slot of the all-zero record the lists are padded with
 // ------------------------------------------------------------------------------------------------------------------
-// Backward, list-driven (the kernel that runs): one wave per tile, every 16-lane group (a DPP row) owns one 8x8
-// sub-block -- lane q of the group holds the 2x2 pixel quad (2 (q & 3), 2 (q >> 2)) of it -- and walks its OWN list of
-// the round's instances that reach the sub-block, back to front.  One wave instruction works on four different
-// (instance, sub-block) pairs, and the per-instance scalar control of round 1's wave-per-instance loop (mask read-out,
-// four bit tests, EXEC juggling: 45 % of that kernel's time) is gone.  The nine sums of a pair are folded
-// over the 16-lane row with DPP only and added into the wave's LDS slab [instance][9], from which the staging lanes
-// write whole 48-byte rows at the end of the round.  Still no atomics, still bitwise reproducible: a slab word is
-// added to in list order, and when two groups hold the same instance at the same step they go in group order.
+// Backward, sixteen lists per wave: every 4-lane DPP bank owns one 4x4 MINI-BLOCK (lane j of bank mb holds the 2x2 quad
+// (2 (j & 1), 2 (j >> 1)) of mini-block mb, mb = 4 * block row + block column as miniblock_mask numbers them) and walks
+// its own list: one wave instruction works on SIXTEEN (instance, mini-block) pairs.  For 7-pixel footprints a pair of a
+// 4x4 block has half of its pixels above the alpha threshold (an 8x8 pair: a quarter), so the walk needs 0.64x the steps
+// (tools/sim_bwd_lists.py) at the same cost per step.
+// With sixteen banks the same instance is met by several banks in the same step all the time, so the banks do not add
+// into a shared row: the fold over the bank's four lanes goes to a slot of its own, [list][list position], and after the
+// walk the staging lane of every instance sums its slots in mini-block order (float; a fixed order per instance, so the
+// row does not depend on what else shares the round).  Slots exist for MB_WIN list positions; a round in which a list is
+// longer is done in passes: a pass takes the instances from the back for which every list still fits
+// (an instance's pairs are never split over passes).
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int SB_DUMMY = WAVE;                 // LDS slot of the all-zero record the lists are padded with
-constexpr int SB_LIST = WAVE + 8;              // list capacity (entries past the longest list are read, never used)
-constexpr int SB_SLAB = 5 * 2 * WAVE;          // doubles: 65 x 9 = 585 used, a multiple of 64 x 16 bytes for the zero-fill
-struct SbLds {
+#ifdef BWD_PROFILE
+// variant build only (tools/bwd_profile.py): shader-clock cycles per section, summed over all waves
+__device__ unsigned long long g_bwd_prof[8];
+#define PROF_T(x) const unsigned long long x = __builtin_readcyclecounter()
+#define PROF_ADD(k, a, b) prof[k] += (unsigned long long)((b) - (a))
+#define PROF_CNT(k, n) prof[k] += (unsigned long long)(n)
+#else
+#define PROF_T(x)
+#define PROF_ADD(k, a, b)
+#define PROF_CNT(k, n)
+#endif
+constexpr int MB_WIN = 26;                   // list positions a pass can hold
+constexpr int MB_ROW = MB_WIN + 1;           // slot row: [0] stays zero (what an instance reads for a list it is not in), then the
+                                             // positions; 108- / 27-word rows put the sixteen banks' slot writes into distinct LDS banks
+constexpr int MB_LIST = MB_WIN + 2;          // list row: [0] takes the writes of the lanes that are not in the list, then the
+                                             // entries, one entry of read-ahead: 56 bytes
+struct MbLds {
   float4 A[WAVE + 1];
   float4 B[WAVE + 1];
   float C[WAVE + 4];
-  uint16_t list[4][SB_LIST];
-  // The (at most four) sub-block partial sums of a row are added in double: the order in which the groups reach an
-  // instance depends on what else is in the round, and a float sum would make the last bit of a gradient depend on the
-  // binning mode (a double sum of four floats is exact unless their exponents span more than 2^29).
-  double slab[SB_SLAB];
+  __attribute__((aligned(16))) uint16_t list[16][MB_LIST];
+  float4 s0[16][MB_ROW];      // sums 0..3 of the pair at [list][1 + position]
+  float4 s1[16][MB_ROW];      // sums 4..7
+  float s2[16][MB_ROW];       // sum 8
 };
+static_assert((16 * MB_LIST * 2) % 16 == 0 && 16 * MB_LIST * 2 / 16 <= WAVE, "the list block is padded by one 16-byte store per lane");
 
-// Sums of nine values over each 16-lane row with bank-masked DPP adds (v_add_f32_dpp leaves the lanes outside bank_mask
-// untouched, which merges two values into one register without a separate v_mov_dpp): 9 + 5 + 6 = 20 operations -- the
-// builtin form (__builtin_amdgcn_update_dpp + add) needed 26, and a transposition through LDS (13 LDS instructions + 15
-// adds) measured no faster (profiles/r03/ab_fold_c4.txt, ab_fold_c3.txt: fold0 = builtin, fold1 = this, fold2 = LDS).  Result: n0 banks (0,1,2,3) = sums of (v0, v2, v1, v3), n1 banks =
-// sums of (v4, v6, v5, v7), n2 every bank = sum of v8 (each sum in all four lanes of its bank).  v is clobbered.
-// A DPP operand must not have been written by one of the two previous instructions: the order below keeps every
-// producer at least two instructions ahead of its reader, the s_nop covers whatever the compiler placed in front.
-__device__ __forceinline__ void row_fold9_masked(float (&v)[9], float& n0, float& n1, float& n2) {
+// sums of nine values over the four lanes of every DPP bank (all four lanes get them): 18 operations
+__device__ __forceinline__ void quad_fold9(float (&v)[9]) {
   asm volatile(
       "s_nop 1\n\t"
-      // stage 1: lanes l and l+8.  Odd registers keep their own sum in lanes 8-15 and take the even one's in lanes 0-7
-      "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-      "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-      "v_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-      "v_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-      "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-      "v_add_f32_dpp %3, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-      "v_add_f32_dpp %5, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-      "v_add_f32_dpp %7, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-      // stage 2: lanes i and 7-i of each half row.  %3 / %7 keep their own sums in banks 1, 3 and take %1 / %5 in banks 0, 2
-      "v_add_f32_dpp %8, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-      "v_add_f32_dpp %7, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-      "v_add_f32_dpp %3, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-      "v_add_f32_dpp %7, %5, %5 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-      // stage 3: the four lanes of every bank
-      "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
       "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
       "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
       "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %7, %7, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+      "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %6, %6, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %7, %7, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
       : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]));
-  n0 = v[3];
-  n1 = v[7];
-  n2 = v[8];
 }
 
-__device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, int W, int H, int grid_x,
+__device__ __forceinline__ void render_bwd_tile_mb16(const int tile, MbLds& L, int W, int H, int grid_x,
                                                      const uint2* __restrict__ ranges,
                                                      const uint32_t* __restrict__ point_list,
                                                      const GeomRec* __restrict__ rec,
+                                                     const uint16_t* __restrict__ inst_mask,
                                                      const uint32_t* __restrict__ slot_base, const float* __restrict__ bg,
                                                      const float* __restrict__ final_T,
                                                      const uint32_t* __restrict__ n_contrib,
@@ -480,11 +449,9 @@ __device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, i
                                                      const float* __restrict__ dL_dpix, GradRow* __restrict__ rows,
                                                      uint8_t* __restrict__ row_flags) {
   const int lane = threadIdx.x & (WAVE - 1);
-  const int grp = lane >> 4, q = lane & 15;
+  const int mb = lane >> 2, j = lane & 3;
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
-  const float tx0 = (float)(tile_x * TILE), ty0 = (float)(tile_y * TILE);
-  // the lane's 2x2 quad inside sub-block grp (sub-block k: x index k & 1, y index k >> 1, as subblock_mask numbers them)
-  const int px0 = tile_x * TILE + 8 * (grp & 1) + 2 * (q & 3), py0 = tile_y * TILE + 8 * (grp >> 1) + 2 * (q >> 2);
+  const int px0 = tile_x * TILE + 4 * (mb & 3) + 2 * (j & 1), py0 = tile_y * TILE + 4 * (mb >> 2) + 2 * (j >> 1);
   // dx = mean - pixel is formed by ONE subtraction from the exact integer coordinate, as in the forward and the reference
   float pxf0 = (float)px0, pxf1 = (float)(px0 + 1), pyf0 = (float)py0, pyf1 = (float)(py0 + 1);
   asm volatile("" : "+v"(pxf0), "+v"(pxf1), "+v"(pyf0), "+v"(pyf1));      // keep them in registers
@@ -512,26 +479,27 @@ __device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, i
   const uint2 range = ranges[tile];
   const uint32_t start = range.x;
   uint32_t hi = min(range.y - range.x, tile_max[tile]);   // instances past the last contributor get no gradient
-  // the same per 8x8 sub-block (= 16-lane row): a sub-block behind an opaque surface stops long before the rest of the tile
-  uint32_t sub_last[4];
+  // the same per mini-block: lane l < 16 keeps the last contributor of mini-block l (a mini-block behind an opaque
+  // surface leaves the lists long before the rest of the tile)
+  uint32_t mbl;
   {
     uint32_t mx = max(max(last[0], last[1]), max(last[2], last[3]));
-#pragma unroll
-    for (int d = 8; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, WAVE));
-#pragma unroll
-    for (int k = 0; k < 4; ++k) sub_last[k] = (uint32_t)__builtin_amdgcn_readlane((int)mx, 16 * k);
+    mx = max(mx, (uint32_t)__shfl_xor((int)mx, 1, WAVE));
+    mx = max(mx, (uint32_t)__shfl_xor((int)mx, 2, WAVE));
+    mbl = (uint32_t)__shfl((int)mx, (4 * lane) & (WAVE - 1), WAVE);
+    if (lane >= 16) mbl = 0u;
   }
   if (lane == 0) {
-    L.A[SB_DUMMY] = make_float4(0.f, 0.f, 0.f, 0.f);
-    L.B[SB_DUMMY] = make_float4(0.f, -__builtin_inff(), 0.f, 0.f);      // log2(opacity) = -inf: alpha = 0
-    L.C[SB_DUMMY] = 0.0f;
+    L.A[MB_DUMMY] = make_float4(0.f, 0.f, 0.f, 0.f);
+    L.B[MB_DUMMY] = make_float4(0.f, -__builtin_inff(), 0.f, 0.f);      // log2(opacity) = -inf: alpha = 0
+    L.C[MB_DUMMY] = 0.0f;
   }
-  // where this lane's fold results go (row_fold9): banks (0,1,2,3) of n0 / n1 hold values (0,2,1,3) (+4)
-  const int bank = q >> 2, sel = q & 3;
-  const int vsel = (bank == 1) ? 2 : (bank == 2 ? 1 : bank);
-  // slab word this lane adds to: n0 -> values 0..3, n1 -> 4..7, n2 -> 8 (bank 0 only); -1: none
-  const int acc_lane = sel == 0 ? vsel : (sel == 1 ? 4 + vsel : ((sel == 2 && bank == 0) ? 8 : -1));
-  const uint16_t* mylist = &L.list[grp][0];
+  if (lane < 16) {
+    L.s0[lane][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    L.s1[lane][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    L.s2[lane][0] = 0.0f;
+  }
+  const uint16_t* mylist = &L.list[mb][1];
 
   Staged st;
   st.q0 = st.q1 = st.q2 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -540,28 +508,81 @@ __device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, i
   // unconditional, index-clamped staging loads (see the forward kernel): ids two rounds ahead,
   // records one round ahead, walking the list back to front
   auto load_id = [&](uint32_t lo, uint32_t top) { return point_list[start + min(lo + lane, top - 1)]; };
+  // only the words this kernel reads (not cxy, cyy, the extents): the destination register of a load nobody reads gets
+  // recycled by the compiler, and the write to it then has to wait for the load -- right behind the prefetch, exposing
+  // the whole gather latency (see load_staged)
   auto load_rec = [&](uint32_t id) {
-    load_staged<true>(rec, id, st);          // q2.w = tile_mask
-    st.slot_base = slot_base[id];
-    const uint2 rr = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(rec + id) + 48);
+    const char* base = reinterpret_cast<const char*>(rec + id);
+    const float* f = reinterpret_cast<const float*>(base);
+    st.q0.x = f[0]; st.q0.y = f[1]; st.q0.z = f[2];                  // mean x, y, conic xx
+    st.q1.y = f[5]; st.q1.z = f[6]; st.q1.w = f[7]; st.q2.x = f[8];  // opacity, r, g, b
+    st.q2.w = f[11];                                                 // tile_mask
+    const uint4 rr = *reinterpret_cast<const uint4*>(base + 48);     // rect_min, rect_wh, kk, 1 / cov_yy
     st.rect_min = rr.x;
     st.rect_wh = rr.y;
+    st.kk = __uint_as_float(rr.z);
+    st.isyy = __uint_as_float(rr.w);
+    st.slot_base = slot_base[id];
   };
+  // the forward's mini-block reach mask of the instance at a list position (coalesced 2-byte reads, one round ahead)
+  auto load_mask = [&](uint32_t lo, uint32_t top) { return (uint32_t)inst_mask[start + min(lo + lane, top - 1)]; };
+  uint32_t mask_next = 0;
   uint32_t lo = hi > BATCH ? hi - BATCH : 0u;
   uint32_t id_next = 0;
   if (hi > 0) {
     load_rec(load_id(lo, hi));
+    mask_next = load_mask(lo, hi);
     const uint32_t lo2 = lo > BATCH ? lo - BATCH : 0u;
     id_next = load_id(lo2, max(lo, 1u));
   }
 
+  // Rows of the most recent pass: every instance sums the slots of its pairs in mini-block order (lanes outside the pass
+  // and lists an instance is not in read the zero slot) and writes one row if it received anything (all-zero sums: no
+  // row, the flag byte stays 0).
+  bool pending = false;
+  uint32_t p_idx[4] = {0u, 0u, 0u, 0u}, p_slot = 0u;
+  float p_lo2op = 0.0f;
+  auto flush_rows = [&]() {
+    __builtin_amdgcn_wave_barrier();
+    {
+      float r9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t at = (p_idx[r] >> (8 * k)) & 0xffu;
+          const float4 f = L.s0[4 * r + k][at], g = L.s1[4 * r + k][at];
+          const float hh = L.s2[4 * r + k][at];
+          r9[0] += f.x; r9[1] += f.y; r9[2] += f.z; r9[3] += f.w;
+          r9[4] += g.x; r9[5] += g.y; r9[6] += g.z; r9[7] += g.w;
+          r9[8] += hh;
+        }
+      uint32_t bits = 0u;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) bits |= __float_as_uint(r9[t]);
+      const bool nz = (bits << 1) != 0u;      // lanes outside the pass read zero slots only
+      if (nz) {
+        float4* dst = reinterpret_cast<float4*>(rows + p_slot);
+        dst[0] = make_float4(r9[0], r9[1], -0.5f * r9[2], -r9[3]);                                   // Mx, My, dcxx, dcxy
+        dst[1] = make_float4(-0.5f * r9[4], r9[5] * __builtin_amdgcn_exp2f(-p_lo2op), r9[6], r9[7]);   // dcyy, dop, dr, dg
+        dst[2] = make_float4(r9[8], 0.f, 0.f, 0.f);                                                  // db
+        row_flags[p_slot] = 1;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+#ifdef BWD_PROFILE
+  unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  PROF_T(t_tile0);
   while (hi > 0) {
+    PROF_T(t_r0);
+    PROF_CNT(4, 1);
     const uint32_t cur_lo = lo;
     const bool have = lo + lane < hi;
-    // sub-blocks that still have a contributor in this round (1-based indices cur_lo + 1 .. hi)
-    const uint32_t active = (sub_last[0] > cur_lo ? 1u : 0u) | (sub_last[1] > cur_lo ? 2u : 0u) |
-                            (sub_last[2] > cur_lo ? 4u : 0u) | (sub_last[3] > cur_lo ? 8u : 0u);
-    const uint32_t m = (have ? subblock_mask(st.q0.x, st.q0.y, st.q2.y, st.q2.z, st.q0.z, st.q0.w, st.q1.x, st.q1.y, tx0, ty0) : 0u) & active;
+    // mini-blocks that still have a contributor in this round (1-based indices cur_lo + 1 .. hi)
+    const uint32_t active = (uint32_t)__builtin_amdgcn_ballot_w64(mbl > cur_lo);
+    const uint32_t m = have ? (mask_next & active) : 0u;
     // the 0.99 clamp can only be reached by an opacity above it (to the ulp of v_log / v_exp)
     const bool clamp = __builtin_amdgcn_ballot_w64(m != 0u && st.q1.y > ALPHA_MAX) != 0ull;
     // gradient-row slot of this instance: the Gaussian's first slot + the rank of this tile among its instances
@@ -570,147 +591,174 @@ __device__ __forceinline__ void render_bwd_tile_sb16(const int tile, SbLds& L, i
     const uint32_t slot = st.slot_base + bin_rank(st.rect_wh, __float_as_uint(st.q2.w), have ? bit : 0u);
     LdsRec lr;
     make_lds(st, lr);
-    const float lo2op = lr.B.y;                      // log2(opacity): 1 / opacity for the row at the end of the round
+    const float lo2op = lr.B.y;                      // log2(opacity): 1 / opacity for the row at the end of the pass
     __builtin_amdgcn_wave_barrier();
     L.A[lane] = lr.A;
     L.B[lane] = lr.B;
     L.C[lane] = st.q2.x;
-    {   // zero the slab, pad the lists
-      float4* z = reinterpret_cast<float4*>(L.slab);
-#pragma unroll
-      for (int t = 0; t < SB_SLAB * 8 / (16 * WAVE); ++t) z[t * WAVE + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-      const uint32_t dd = 16u * SB_DUMMY * 0x10001u;
-      uint4* l4 = reinterpret_cast<uint4*>(&L.list[0][0]);
-      if (lane < 4 * SB_LIST * 2 / 16) l4[lane] = make_uint4(dd, dd, dd, dd);
-    }
-    __builtin_amdgcn_wave_barrier();
-    // lists back to front: the highest lane (latest list position) first
-    uint32_t nmax = 0;
-    const unsigned long long above = ~((2ull << lane) - 1ull);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const bool mine = (m >> k) & 1u;
-      const unsigned long long bal = __builtin_amdgcn_ballot_w64(mine);
-      nmax = max(nmax, (uint32_t)__popcll(bal));
-      if (mine) L.list[k][__popcll(bal & above)] = (uint16_t)(16 * lane);
-    }
     hi = lo;
     lo = hi > BATCH ? hi - BATCH : 0u;
-    {   // prefetch: record of the next (earlier) round, ids of the one after it
+    {   // prefetch: record and mask of the next (earlier) round, ids of the one after it
       load_rec(id_next);
+      mask_next = load_mask(lo, max(hi, 1u));
       const uint32_t lo2 = lo > BATCH ? lo - BATCH : 0u;
       id_next = load_id(lo2, max(lo, 1u));
     }
-    __builtin_amdgcn_wave_barrier();
-    // steps at which two of the four lists hold the same instance (lane i looks at step i): those add to the slab one
-    // group after the other
-    unsigned long long clash;
-    {
-      const uint32_t a = L.list[0][lane], b = L.list[1][lane], c = L.list[2][lane], d = L.list[3][lane];
-      const uint32_t dm = 16u * SB_DUMMY;
-      clash = __builtin_amdgcn_ballot_w64((a != dm && (a == b || a == c || a == d)) || (b != dm && (b == c || b == d)) ||
-                                          (c != dm && c == d));
-    }
-    // two copies of the walk: the 0.99 clamp costs an instruction per pixel and almost no round needs it.  (A third copy
-    // for rounds in which no pixel's last contributor lies strictly inside -- a per-pixel alpha threshold of 1/255 or +inf
-    // instead of the position compare -- was measured: no gain, profiles/r03/ab_bwd_variants_c4.txt "thr".)
-    auto walk = [&](auto clamped_c) {
-      constexpr bool CLAMPED = decltype(clamped_c)::value;
-      uint32_t e0 = mylist[0];
-      for (uint32_t i = 0; i < nmax; ++i) {
-        const uint32_t e1 = mylist[i + 1];
-        const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(L.A) + e0);
-        const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(L.B) + e0);
-        const float cb = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(L.C) + (e0 >> 2));
-        const uint32_t pos1 = cur_lo + (e0 >> 4) + 1u;
-        // per-lane partial sums over the quad; un-scaled forms (constants applied to the row):
-        //   v0 = sum h dx, v1 = sum h dy (first moments), v2 = sum h dx^2, v3 = sum h dx dy, v4 = sum h dy^2 with
-        //   h = opacity*G*dL_dalpha;  v5 = sum h (= opacity * dL_dopacity);  v6..8 = sum alpha*T*dL_dpix
-        float v[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        float S = 0.f, Sx = 0.f, Sy = 0.f, Sxy = 0.f;
-  #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const bool live = pos1 <= last[k];
-          if (__builtin_amdgcn_ballot_w64(live) == 0ull) continue;      // every pixel of this quad position is past its last contributor
-          const float dx = a.x - ((k & 1) ? pxf1 : pxf0), dy = a.y - ((k >> 1) ? pyf1 : pyf0);
-          const float ar = __builtin_amdgcn_exp2f(pair_p2(dx, dy, a.z, a.w, b.x, b.y));      // opacity * G
-          const bool ok = live && (ar >= ALPHA_MIN);        // (the clamp is above the threshold: same test on either)
-          // lanes that do not contribute run the same instructions on alpha = 0: 1 / (1 - 0) = 1 and every product is 0
-          const float arm = ok ? ar : 0.0f;
-          const float am = CLAMPED ? clamp_alpha(arm, b.x) : arm;
-          const float rcp = __builtin_amdgcn_rcpf(1.0f - am);
-          T[k] *= rcp;                                   // transmittance in front of this instance
-          const float D = fmaf(cb, dpb[k], fmaf(b.w, dpg[k], fmaf(b.z, dpr[k], -U[k])));   // c . dL_dpix - U
-          const float dch = am * T[k];
-          // opacity * G * dL_dalpha with dL_dalpha = T D: the clamp passes the gradient on (arm, not am).  Same
-          // association in both copies of the walk: which one an instance meets depends on what else is in its round
-          const float h = (CLAMPED ? arm * T[k] : dch) * D;
-          U[k] = fmaf(am, D, U[k]);
-          // moments of h about the quad's first pixel: the offsets of the other three are 0 / 1, so h itself is all that
-          // is added per pixel (dx_k = dx_0 - (k & 1) and dy_k = dy_0 - (k >> 1) exactly: all four differences are exact)
-          S += h;
-          if (k & 1) Sx += h;
-          if (k >> 1) Sy += h;
-          if (k == 3) Sxy = h;
-          v[6] = fmaf(dch, dpr[k], v[6]); v[7] = fmaf(dch, dpg[k], v[7]); v[8] = fmaf(dch, dpb[k], v[8]);
-        }
-        {   // sum h dx = dx0 S - Sx, sum h dx^2 = dx0 (dx0 S - 2 Sx) + Sx, sum h dx dy = dx0 (dy0 S - Sy) - dy0 Sx + Sxy, ...
-          const float dx0 = a.x - pxf0, dy0 = a.y - pyf0;
-          v[0] = fmaf(dx0, S, -Sx);
-          v[1] = fmaf(dy0, S, -Sy);
-          v[2] = fmaf(dx0, v[0] - Sx, Sx);
-          v[4] = fmaf(dy0, v[1] - Sy, Sy);
-          v[3] = fmaf(dx0, v[1], fmaf(-dy0, Sx, Sxy));
-          v[5] = S;
-        }
-        float n0, n1, n2;
-        row_fold9_masked(v, n0, n1, n2);
-        // lane j of bank k takes the bank's value of n0 (j = 0), n1 (j = 1), n2 (j = 2, bank 0 only): the nine sums of the
-        // row sit in nine lanes and go to the slab with one read-add-write (LDS float atomics retire about one lane per
-        // cycle per CU: far slower)
-        const float nn = (sel == 0) ? n0 : (sel == 1 ? n1 : n2);
-        double* dst = L.slab + 9 * (e0 >> 4) + (acc_lane < 0 ? 0 : acc_lane);
-        const bool adds = acc_lane >= 0;
-        if (!((clash >> i) & 1ull)) {
-          if (adds) *dst += (double)nn;
-        } else {
-  #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            if (adds && grp == g) *dst += (double)nn;
-            __builtin_amdgcn_wave_barrier();     // LDS operations of one wave execute in order
-          }
-        }
-        e0 = e1;
-      }
-    };
-    if (clamp) walk(std::true_type{}); else walk(std::false_type{});
-    __builtin_amdgcn_wave_barrier();
-    // one row per staged instance that received anything (all-zero sums: no row, the flag byte stays 0)
-    if (m != 0u) {
-      const double* s9 = L.slab + 9 * lane;
-      float r9[9];
-      bool nz = false;
+    unsigned long long remaining = __builtin_amdgcn_ballot_w64(m != 0u);
+    PROF_T(t_r1);
+    PROF_ADD(0, t_r0, t_r1);
+    while (remaining != 0ull) {
+      PROF_T(t_p0);
+      PROF_CNT(5, 1);
+      // ---- which instances this pass takes, their list positions ---------------------------------------------------
+      const bool rem = (remaining >> lane) & 1ull;
+      const uint32_t mr = rem ? m : 0u;
+      // sfx[r], byte k: members of list 4 r + k among the remaining lanes >= this one (back to front: the highest lane
+      // is the first entry).  Four packed 8-bit counters per register, as in the forward.
+      uint32_t sfx[4], own[4], over = 0u;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) { r9[t] = (float)s9[t]; nz = nz || r9[t] != 0.0f; }
-      if (nz) {
-        float4* dst = reinterpret_cast<float4*>(rows + slot);
-        dst[0] = make_float4(r9[0], r9[1], -0.5f * r9[2], -r9[3]);                                   // Mx, My, dcxx, dcxy
-        dst[1] = make_float4(-0.5f * r9[4], r9[5] * __builtin_amdgcn_exp2f(-lo2op), r9[6], r9[7]);   // dcyy, dop, dr, dg
-        dst[2] = make_float4(r9[8], 0.f, 0.f, 0.f);                                                  // db
-        row_flags[slot] = 1;
+      for (int r = 0; r < 4; ++r) {
+        own[r] = (((mr >> (4 * r)) & 0xfu) * 0x00204081u) & 0x01010101u;
+        const uint32_t incl = wave_incl_scan_dpp(own[r]);
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
+        sfx[r] = tot - incl + own[r];
+        over |= sfx[r] + (uint32_t)(127 - MB_WIN) * 0x01010101u;      // bit 7 of a byte: that list is past the window here
       }
+      const bool inA = rem && (over & 0x80808080u) == 0u;             // the top remaining lane always is
+      const unsigned long long balA = __builtin_amdgcn_ballot_w64(inA);
+      // list lengths of the pass = the counters at its lowest lane; the longest one sets the number of steps
+      uint32_t nmax;
+      {
+        const int cA = __builtin_ctzll(balA);
+        const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)sfx[0], cA), c1 = (uint32_t)__builtin_amdgcn_readlane((int)sfx[1], cA);
+        const uint32_t c2 = (uint32_t)__builtin_amdgcn_readlane((int)sfx[2], cA), c3 = (uint32_t)__builtin_amdgcn_readlane((int)sfx[3], cA);
+        const uint32_t csel = (lane & 8) ? ((lane & 4) ? c3 : c2) : ((lane & 4) ? c1 : c0);
+        uint32_t len = (csel >> (8 * (lane & 3))) & 0xffu;            // lanes 0..15: length of list `lane`
+        len = max(len, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)len, 0x128, 0xf, 0xf, false));   // row_ror:8
+        len = max(len, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)len, 0x124, 0xf, 0xf, false));   // row_ror:4
+        len = max(len, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)len, 0x122, 0xf, 0xf, false));   // row_ror:2
+        len = max(len, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)len, 0x121, 0xf, 0xf, false));   // row_ror:1
+        nmax = (uint32_t)__builtin_amdgcn_readlane((int)len, 0);
+      }
+      // idx[r], byte k: 1 + this instance's position in list 4 r + k, 0 for a list it is not in (or not in this pass): the
+      // row index of its list entry and of its slot -- index 0 is the junk entry / the zero slot, so neither the list
+      // build nor the sums below need a branch or a predicate
+      uint32_t idx[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) idx[r] = inA ? (sfx[r] & (own[r] * 0xffu)) : 0u;
+      __builtin_amdgcn_wave_barrier();
+      {   // pad the lists with the dummy record
+        const uint32_t dd = 16u * MB_DUMMY * 0x10001u;
+        uint4* l4 = reinterpret_cast<uint4*>(&L.list[0][0]);
+        if (lane < 16 * MB_LIST * 2 / 16) l4[lane] = make_uint4(dd, dd, dd, dd);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) L.list[4 * r + k][(idx[r] >> (8 * k)) & 0xffu] = (uint16_t)(16 * lane);
+      __builtin_amdgcn_wave_barrier();
+      // two copies of the walk: the 0.99 clamp costs an instruction per pixel and almost no round needs it
+      auto walk = [&](auto clamped_c) {
+        constexpr bool CLAMPED = decltype(clamped_c)::value;
+        uint32_t e0 = mylist[0];
+        for (uint32_t i = 0; i < nmax; ++i) {
+          const uint32_t e1 = mylist[i + 1];
+          const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(L.A) + e0);
+          const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(L.B) + e0);
+          const float cb = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(L.C) + (e0 >> 2));
+          const uint32_t pos1 = cur_lo + (e0 >> 4) + 1u;
+          // per-lane partial sums over the quad; un-scaled forms (constants applied to the row):
+          //   v0 = sum h dx, v1 = sum h dy (first moments), v2 = sum h dx^2, v3 = sum h dx dy, v4 = sum h dy^2 with
+          //   h = opacity*G*dL_dalpha;  v5 = sum h (= opacity * dL_dopacity);  v6..8 = sum alpha*T*dL_dpix
+          float v[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          float S = 0.f, Sx = 0.f, Sy = 0.f, Sxy = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const bool live = pos1 <= last[k];
+            // (no wave-wide skip of a quad position whose 64 pixels are all past their last contributor: with sixteen
+            // mini-blocks in the wave that never happens, and the branch kept the four evaluations from being interleaved:
+            // -5 % without it, profiles/r03/ab_bwd_mb16.txt)
+            const float dx = a.x - ((k & 1) ? pxf1 : pxf0), dy = a.y - ((k >> 1) ? pyf1 : pyf0);
+            const float ar = __builtin_amdgcn_exp2f(pair_p2(dx, dy, a.z, a.w, b.x, b.y));      // opacity * G
+            const bool ok = live && (ar >= ALPHA_MIN);        // (the clamp is above the threshold: same test on either)
+            // lanes that do not contribute run the same instructions on alpha = 0: 1 / (1 - 0) = 1 and every product is 0
+            const float arm = ok ? ar : 0.0f;
+            const float am = CLAMPED ? clamp_alpha(arm, b.x) : arm;
+            const float rcp = __builtin_amdgcn_rcpf(1.0f - am);
+            T[k] *= rcp;                                   // transmittance in front of this instance
+            const float D = fmaf(cb, dpb[k], fmaf(b.w, dpg[k], fmaf(b.z, dpr[k], -U[k])));   // c . dL_dpix - U
+            const float dch = am * T[k];
+            // opacity * G * dL_dalpha with dL_dalpha = T D: the clamp passes the gradient on (arm, not am).  Same
+            // association in both copies of the walk: which one an instance meets depends on what else is in its round
+            const float h = (CLAMPED ? arm * T[k] : dch) * D;
+            U[k] = fmaf(am, D, U[k]);
+            // moments of h about the quad's first pixel: the offsets of the other three are 0 / 1, so h itself is all that
+            // is added per pixel (dx_k = dx_0 - (k & 1) and dy_k = dy_0 - (k >> 1) exactly: all four differences are exact)
+            S += h;
+            if (k & 1) Sx += h;
+            if (k >> 1) Sy += h;
+            if (k == 3) Sxy = h;
+            v[6] = fmaf(dch, dpr[k], v[6]); v[7] = fmaf(dch, dpg[k], v[7]); v[8] = fmaf(dch, dpb[k], v[8]);
+          }
+          {   // sum h dx = dx0 S - Sx, sum h dx^2 = dx0 (dx0 S - 2 Sx) + Sx, sum h dx dy = dx0 (dy0 S - Sy) - dy0 Sx + Sxy, ...
+            const float dx0 = a.x - pxf0, dy0 = a.y - pyf0;
+            v[0] = fmaf(dx0, S, -Sx);
+            v[1] = fmaf(dy0, S, -Sy);
+            v[2] = fmaf(dx0, v[0] - Sx, Sx);
+            v[4] = fmaf(dy0, v[1] - Sy, Sy);
+            v[3] = fmaf(dx0, v[1], fmaf(-dy0, Sx, Sxy));
+            v[5] = S;
+          }
+          quad_fold9(v);
+          if (j == 0) {      // the pair's nine sums: one slot per (list, position), nobody else writes it
+            L.s0[mb][i + 1] = make_float4(v[0], v[1], v[2], v[3]);
+            L.s1[mb][i + 1] = make_float4(v[4], v[5], v[6], v[7]);
+            L.s2[mb][i + 1] = v[8];
+          }
+          e0 = e1;
+        }
+      };
+      PROF_T(t_p1);
+      PROF_ADD(1, t_p0, t_p1);
+      PROF_CNT(6, nmax);
+      if (pending) flush_rows();
+      PROF_T(t_p1b);
+      PROF_ADD(3, t_p1, t_p1b);
+      if (clamp) walk(std::true_type{}); else walk(std::false_type{});
+      __builtin_amdgcn_wave_barrier();
+      PROF_T(t_p2);
+      PROF_ADD(2, t_p1b, t_p2);
+      // the rows of this pass are summed and written when its slots are about to be reused (flush_rows): the stores
+      // are then in flight during a walk instead of in front of the next round's wait for its records
+      pending = true;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p_idx[r] = idx[r];
+      p_slot = slot;
+      p_lo2op = lo2op;
+      remaining &= ~balA;
     }
   }
+  if (pending) flush_rows();
+#ifdef BWD_PROFILE
+  {
+    PROF_T(t_tile1);
+    prof[7] = t_tile1 - t_tile0;
+    if (lane == 0)
+      for (int k = 0; k < 8; ++k) atomicAdd(&g_bwd_prof[k], prof[k]);
+  }
+#endif
 }
 
-#ifndef BWD_WAVES
-#define BWD_WAVES 4
-#endif
+// 19 KB of LDS per wave: two blocks of four waves per CU.  The kernel is bound by vector instruction issue and two waves
+// per SIMD keep it issuing (profiles/r03/ab_render_bwd_occupancy.txt)
+constexpr int BWD_WAVES = 2;
 __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE, BWD_WAVES) void render_bwd_kernel(int W, int H, int grid_x, int num_tiles,
                                                           const uint32_t* __restrict__ tile_order,
                                                           const uint2* __restrict__ ranges,
                                                           const uint32_t* __restrict__ point_list,
                                                           const GeomRec* __restrict__ rec,
+                                                          const uint16_t* __restrict__ inst_mask,
                                                           const uint32_t* __restrict__ slot_base,
                                                           const float* __restrict__ bg,
                                                           const float* __restrict__ final_T,
@@ -719,18 +767,18 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE, BWD_WAVES) void render_bwd_
                                                           const float* __restrict__ dL_dpix,
                                                           GradRow* __restrict__ rows,
                                                           uint8_t* __restrict__ row_flags) {
-  __shared__ SbLds sL[WAVES_PER_BLOCK];
+  __shared__ MbLds sL[WAVES_PER_BLOCK];
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
   const int slot = blockIdx.x * WAVES_PER_BLOCK + wid;
   if (slot >= num_tiles) return;
   const int tile = __builtin_amdgcn_readfirstlane((int)tile_order[slot]);
-  render_bwd_tile_sb16(tile, sL[wid], W, H, grid_x, ranges, point_list, rec, slot_base, bg, final_T, n_contrib, tile_max,
+  render_bwd_tile_mb16(tile, sL[wid], W, H, grid_x, ranges, point_list, rec, inst_mask, slot_base, bg, final_T, n_contrib, tile_max,
                        dL_dpix, rows, row_flags);
 }
 
 void launch_render_fwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
                        const float* bg, float* out_color, float* final_T, uint32_t* n_contrib, uint32_t* tile_max,
-                       const uint32_t* tile_order, hipStream_t s, unsigned long long* stats, int cull) {
+                       const uint32_t* tile_order, hipStream_t s, unsigned long long* stats, int cull, uint16_t* inst_mask) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   const int nblk = gx * gy;       // one 256-lane workgroup per tile, longest list first
   // cull = 0 (GsrParams.debug_flags & GSR_DEBUG_NO_MINIBLOCK_CULL, tests/test_gpu_miniblock_cull.py): every staged
@@ -738,22 +786,33 @@ void launch_render_fwd(int W, int H, const uint2* ranges, const uint32_t* point_
   // passes the alpha test)
   if (stats)
     hipLaunchKernelGGL((render_fwd_kernel<true, true>), dim3(nblk), dim3(256), 0, s, W, H, gx, cull, tile_order, ranges,
-                       point_list, rec, bg, out_color, final_T, n_contrib, tile_max, stats);
-  else if (final_T && n_contrib && tile_max)
+                       point_list, rec, bg, out_color, final_T, n_contrib, tile_max, inst_mask, stats);
+  else if (final_T && n_contrib && tile_max)      // inst_mask may be NULL only for a frame without instances
     hipLaunchKernelGGL((render_fwd_kernel<false, true>), dim3(nblk), dim3(256), 0, s, W, H, gx, cull, tile_order, ranges,
-                       point_list, rec, bg, out_color, final_T, n_contrib, tile_max, stats);
+                       point_list, rec, bg, out_color, final_T, n_contrib, tile_max, inst_mask, stats);
   else      // forward only: no per-pixel state for a backward
     hipLaunchKernelGGL((render_fwd_kernel<false, false>), dim3(nblk), dim3(256), 0, s, W, H, gx, cull, tile_order, ranges,
-                       point_list, rec, bg, out_color, final_T, n_contrib, tile_max, stats);
+                       point_list, rec, bg, out_color, final_T, n_contrib, tile_max, inst_mask, stats);
 }
+#ifdef BWD_PROFILE
+extern "C" int gsr_debug_bwd_profile(unsigned long long* out8, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bwd_prof), 64) != hipSuccess) return 2;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_prof), z, 64) != hipSuccess) return 3;
+  }
+  return 0;
+}
+#endif
 void launch_render_bwd(int W, int H, const uint2* ranges, const uint32_t* point_list, const GeomRec* rec,
                        const uint32_t* slot_base, const float* bg, const float* final_T, const uint32_t* n_contrib, const uint32_t* tile_max,
                        const float* dL_dpix, GradRow* rows, uint8_t* row_flags, const uint32_t* tile_order,
-                       hipStream_t s) {
+                       hipStream_t s, const uint16_t* inst_mask) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   const int nblk = (gx * gy + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
   hipLaunchKernelGGL(render_bwd_kernel, dim3(nblk), dim3(WAVES_PER_BLOCK * WAVE), 0, s, W, H, gx, gx * gy, tile_order, ranges, point_list, rec,
-                     slot_base, bg, final_T, n_contrib, tile_max, dL_dpix, rows, row_flags);
+                     inst_mask, slot_base, bg, final_T, n_contrib, tile_max, dL_dpix, rows, row_flags);
 }
 
 }  // namespace gsr

@@ -1,0 +1,9 @@
+#!/bin/bash
+OUT=gpurun_out/r03ab; mkdir -p $OUT
+timeout -k 10 800 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest.log
+for r in 1 2; do for v in bwd_sb16 bwd_mb16c; do
+  echo "== $v (round $r)"
+  for c in C4 C3 C2; do GSR_LIB_PATH=$PWD/tools/ab/$v.so PYTHONPATH=.:tools timeout -k 10 200 python tools/kernel_bench.py $c 20 --fused 2>/dev/null | grep -E "render_bwd|render_fwd|bwd="; done
+  GSR_LIB_PATH=$PWD/tools/ab/$v.so PYTHONPATH=.:tools timeout -k 10 200 python tools/bench_heavy_tail.py 6000000 5 2>/dev/null | grep -E "render_bwd|render_fwd"
+done; done | tee $OUT/ab_bwd_mb16.txt
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_c4.json 2> $OUT/bench_c4.err; tail -c 1500 $OUT/bench_c4.json
