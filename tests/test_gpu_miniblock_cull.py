@@ -74,3 +74,41 @@ def test_needles_at_every_orientation(gpu_device, monkeypatch, ratio):
     a, b = _both(gpu_device, monkeypatch, model, cam, torch.tensor([0.0, 0.0, 0.0]), 0)
     assert int((a["n_contrib"] > 0).sum()) > 5000
     _identical(a, b)
+
+
+def _grads(dev, monkeypatch, flags, model, cam, bg, deg, target, scale_modifier=1.0):
+    from gpu_util import grads_product, product_settings
+    from mvs_gaussian_splatting_amd import rasterizer
+    monkeypatch.setattr(rasterizer, "_debug_flags_value", flags)
+    st = product_settings(cam, bg, deg, dev, scale_modifier=scale_modifier)
+    g, col = grads_product(dev, model, st, target.to(dev), torch.ones_like(target).to(dev))
+    monkeypatch.setattr(rasterizer, "_debug_flags_value", 0)
+    return g, col
+
+
+@pytest.mark.parametrize("which", ["cloud", "dense", "soup"])
+def test_backward_does_not_depend_on_the_lists(gpu_device, monkeypatch, which):
+    """The backward walks the forward's (instance, mini-block) pairs.  With the cull off every instance sits in all 16
+    lists of its tile: every round overflows the 26 list positions a pass can hold and is done in three passes, every
+    instance sums 16 slots instead of two or three.  The extra pairs contribute exact zeros and an instance's slots are
+    summed in mini-block order whatever else shares its round, so every gradient must come out BIT-IDENTICAL."""
+    from mvs_gaussian_splatting_amd import _lib
+    if which == "soup":
+        from test_gpu_parity import _stress_model
+        from mvs_gaussian_splatting_amd.synthetic import orbit_camera
+        model, deg, sm = _stress_model(), 2, 1.3
+        cam = orbit_camera(1, 8, 208, 136, 120.0, 120.0)
+        bg = torch.tensor([0.2, 0.4, 0.1])
+    else:
+        # "dense": footprints of tens of pixels, lists of more than 26 entries with the cull ON as well
+        model, cam, bg, _ = small_scene(P=6000, sh_degree=1, width=243, height=139, scale=0.02 if which == "cloud" else 0.15,
+                                        seed=11, view=2)
+        deg, sm = 1, 1.0
+        bg = torch.tensor([0.1, 0.2, 0.3])
+    target = torch.rand(3, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(5))
+    ga, ca = _grads(gpu_device, monkeypatch, 0, model, cam, bg, deg, target, sm)
+    gb, cb = _grads(gpu_device, monkeypatch, _lib.DEBUG_NO_MINIBLOCK_CULL, model, cam, bg, deg, target, sm)
+    assert torch.equal(ca, cb)
+    assert float(ga["xyz"].abs().max()) > 0
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k
