@@ -399,16 +399,17 @@ __device__ unsigned long long g_bwd_prof[8];
 constexpr int MB_WIN = 26;                   // list positions a pass can hold
 constexpr int MB_ROW = MB_WIN + 1;           // slot row: [0] stays zero (what an instance reads for a list it is not in), then the
                                              // positions; 108- / 27-word rows put the sixteen banks' slot writes into distinct LDS banks
-constexpr int MB_LIST = MB_WIN + 2;          // list row: [0] takes the writes of the lanes that are not in the list, then the
-                                             // entries, one entry of read-ahead: 56 bytes
+constexpr int MB_LIST = MB_WIN + 4;          // list row: [0] takes the writes of the lanes that are not in the list, then the
+                                             // entries, two entries of read-ahead: 60 bytes
 struct MbLds {
-  float4 A[WAVE + 1];
-  float4 B[WAVE + 1];
-  float C[WAVE + 4];
+  struct Rec { float4 A, B; float C; float pad[3]; } R[WAVE + 1];      // one 48-byte record: one address per list entry
   __attribute__((aligned(16))) uint16_t list[16][MB_LIST];
   float4 s0[16][MB_ROW];      // sums 0..3 of the pair at [list][1 + position]
   float4 s1[16][MB_ROW];      // sums 4..7
   float s2[16][MB_ROW];       // sum 8
+#ifdef BWD_LDS_PAD
+  char occupancy_probe[BWD_LDS_PAD];
+#endif
 };
 static_assert((16 * MB_LIST * 2) % 16 == 0 && 16 * MB_LIST * 2 / 16 <= WAVE, "the list block is padded by one 16-byte store per lane");
 
@@ -490,9 +491,9 @@ __device__ __forceinline__ void render_bwd_tile_mb16(const int tile, MbLds& L, i
     if (lane >= 16) mbl = 0u;
   }
   if (lane == 0) {
-    L.A[MB_DUMMY] = make_float4(0.f, 0.f, 0.f, 0.f);
-    L.B[MB_DUMMY] = make_float4(0.f, -__builtin_inff(), 0.f, 0.f);      // log2(opacity) = -inf: alpha = 0
-    L.C[MB_DUMMY] = 0.0f;
+    L.R[MB_DUMMY].A = make_float4(0.f, 0.f, 0.f, 0.f);
+    L.R[MB_DUMMY].B = make_float4(0.f, -__builtin_inff(), 0.f, 0.f);      // log2(opacity) = -inf: alpha = 0
+    L.R[MB_DUMMY].C = 0.0f;
   }
   if (lane < 16) {
     L.s0[lane][0] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -593,9 +594,9 @@ __device__ __forceinline__ void render_bwd_tile_mb16(const int tile, MbLds& L, i
     make_lds(st, lr);
     const float lo2op = lr.B.y;                      // log2(opacity): 1 / opacity for the row at the end of the pass
     __builtin_amdgcn_wave_barrier();
-    L.A[lane] = lr.A;
-    L.B[lane] = lr.B;
-    L.C[lane] = st.q2.x;
+    L.R[lane].A = lr.A;
+    L.R[lane].B = lr.B;
+    L.R[lane].C = st.q2.x;
     hi = lo;
     lo = hi > BATCH ? hi - BATCH : 0u;
     {   // prefetch: record and mask of the next (earlier) round, ids of the one after it
@@ -648,7 +649,7 @@ __device__ __forceinline__ void render_bwd_tile_mb16(const int tile, MbLds& L, i
       for (int r = 0; r < 4; ++r) idx[r] = inA ? (sfx[r] & (own[r] * 0xffu)) : 0u;
       __builtin_amdgcn_wave_barrier();
       {   // pad the lists with the dummy record
-        const uint32_t dd = 16u * MB_DUMMY * 0x10001u;
+        const uint32_t dd = (uint32_t)MB_DUMMY * 0x10001u;
         uint4* l4 = reinterpret_cast<uint4*>(&L.list[0][0]);
         if (lane < 16 * MB_LIST * 2 / 16) l4[lane] = make_uint4(dd, dd, dd, dd);
       }
@@ -656,18 +657,25 @@ __device__ __forceinline__ void render_bwd_tile_mb16(const int tile, MbLds& L, i
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) L.list[4 * r + k][(idx[r] >> (8 * k)) & 0xffu] = (uint16_t)(16 * lane);
+        for (int k = 0; k < 4; ++k) L.list[4 * r + k][(idx[r] >> (8 * k)) & 0xffu] = (uint16_t)lane;
       __builtin_amdgcn_wave_barrier();
       // two copies of the walk: the 0.99 clamp costs an instruction per pixel and almost no round needs it
       auto walk = [&](auto clamped_c) {
         constexpr bool CLAMPED = decltype(clamped_c)::value;
-        uint32_t e0 = mylist[0];
+        auto fetch = [&](uint32_t e, float4& a, float4& b, float& cb) {
+          const char* rp = reinterpret_cast<const char*>(L.R) + 48u * e;
+          a = *reinterpret_cast<const float4*>(rp);
+          b = *reinterpret_cast<const float4*>(rp + 16);
+          cb = *reinterpret_cast<const float*>(rp + 32);
+        };
+        uint32_t e0 = mylist[0], e1 = mylist[1];
+        float4 a, b, an, bn;
+        float cb, cbn;
+        fetch(e0, a, b, cb);
         for (uint32_t i = 0; i < nmax; ++i) {
-          const uint32_t e1 = mylist[i + 1];
-          const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(L.A) + e0);
-          const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(L.B) + e0);
-          const float cb = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(L.C) + (e0 >> 2));
-          const uint32_t pos1 = cur_lo + (e0 >> 4) + 1u;
+          fetch(e1, an, bn, cbn);                       // the next pair's record, while this one is evaluated
+          const uint32_t e2 = mylist[i + 2];
+          const uint32_t pos1 = cur_lo + e0 + 1u;
           // per-lane partial sums over the quad; un-scaled forms (constants applied to the row):
           //   v0 = sum h dx, v1 = sum h dy (first moments), v2 = sum h dx^2, v3 = sum h dx dy, v4 = sum h dy^2 with
           //   h = opacity*G*dL_dalpha;  v5 = sum h (= opacity * dL_dopacity);  v6..8 = sum alpha*T*dL_dpix
@@ -675,13 +683,13 @@ __device__ __forceinline__ void render_bwd_tile_mb16(const int tile, MbLds& L, i
           float S = 0.f, Sx = 0.f, Sy = 0.f, Sxy = 0.f;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const bool live = pos1 <= last[k];
             // (no wave-wide skip of a quad position whose 64 pixels are all past their last contributor: with sixteen
             // mini-blocks in the wave that never happens, and the branch kept the four evaluations from being interleaved:
             // -5 % without it, profiles/r03/ab_bwd_mb16.txt)
             const float dx = a.x - ((k & 1) ? pxf1 : pxf0), dy = a.y - ((k >> 1) ? pyf1 : pyf0);
             const float ar = __builtin_amdgcn_exp2f(pair_p2(dx, dy, a.z, a.w, b.x, b.y));      // opacity * G
-            const bool ok = live && (ar >= ALPHA_MIN);        // (the clamp is above the threshold: same test on either)
+            // (the clamp is above the threshold: same test on either)
+            const bool ok = pos1 <= last[k] && ar >= ALPHA_MIN;
             // lanes that do not contribute run the same instructions on alpha = 0: 1 / (1 - 0) = 1 and every product is 0
             const float arm = ok ? ar : 0.0f;
             const float am = CLAMPED ? clamp_alpha(arm, b.x) : arm;
@@ -716,7 +724,8 @@ __device__ __forceinline__ void render_bwd_tile_mb16(const int tile, MbLds& L, i
             L.s1[mb][i + 1] = make_float4(v[4], v[5], v[6], v[7]);
             L.s2[mb][i + 1] = v[8];
           }
-          e0 = e1;
+          e0 = e1; e1 = e2;
+          a = an; b = bn; cb = cbn;
         }
       };
       PROF_T(t_p1);
