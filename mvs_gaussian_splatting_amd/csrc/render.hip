@@ -415,7 +415,7 @@ static_assert((16 * MB_LIST * 2) % 16 == 0 && 16 * MB_LIST * 2 / 16 <= WAVE, "th
 
 // sums of nine values over the four lanes of every DPP bank (all four lanes get them): 18 operations
 __device__ __forceinline__ void quad_fold9(float (&v)[9]) {
-  asm volatile(
+  asm(
       "s_nop 1\n\t"
       "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
       "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
@@ -668,13 +668,8 @@ __device__ __forceinline__ void render_bwd_tile_mb16(const int tile, MbLds& L, i
           b = *reinterpret_cast<const float4*>(rp + 16);
           cb = *reinterpret_cast<const float*>(rp + 32);
         };
-        uint32_t e0 = mylist[0], e1 = mylist[1];
-        float4 a, b, an, bn;
-        float cb, cbn;
-        fetch(e0, a, b, cb);
-        for (uint32_t i = 0; i < nmax; ++i) {
-          fetch(e1, an, bn, cbn);                       // the next pair's record, while this one is evaluated
-          const uint32_t e2 = mylist[i + 2];
+        // one (instance, mini-block) pair per bank: list entry e0 (its record: a, b, cb), list position i
+        auto step = [&](const float4 a, const float4 b, const float cb, const uint32_t e0, const uint32_t i) {
           const uint32_t pos1 = cur_lo + e0 + 1u;
           // per-lane partial sums over the quad; un-scaled forms (constants applied to the row):
           //   v0 = sum h dx, v1 = sum h dy (first moments), v2 = sum h dx^2, v3 = sum h dx dy, v4 = sum h dy^2 with
@@ -719,11 +714,22 @@ __device__ __forceinline__ void render_bwd_tile_mb16(const int tile, MbLds& L, i
             v[5] = S;
           }
           quad_fold9(v);
-          if (j == 0) {      // the pair's nine sums: one slot per (list, position), nobody else writes it
-            L.s0[mb][i + 1] = make_float4(v[0], v[1], v[2], v[3]);
-            L.s1[mb][i + 1] = make_float4(v[4], v[5], v[6], v[7]);
-            L.s2[mb][i + 1] = v[8];
-          }
+          // the pair's nine sums: one slot per (list, position).  After the fold the bank's four lanes hold the same nine
+          // values and all four write them (same address, same data): no EXEC change, the step stays one basic block
+          // (-3 %, profiles/r03/ab_bwd_mb16_step.txt; two steps per iteration in one block: no better, the odd lengths cost
+          // a step)
+          L.s0[mb][i + 1] = make_float4(v[0], v[1], v[2], v[3]);
+          L.s1[mb][i + 1] = make_float4(v[4], v[5], v[6], v[7]);
+          L.s2[mb][i + 1] = v[8];
+        };
+        uint32_t e0 = mylist[0], e1 = mylist[1];
+        float4 a, b, an, bn;
+        float cb, cbn;
+        fetch(e0, a, b, cb);
+        for (uint32_t i = 0; i < nmax; ++i) {
+          fetch(e1, an, bn, cbn);                       // the next pair's record, while this one is evaluated
+          const uint32_t e2 = mylist[i + 2];
+          step(a, b, cb, e0, i);
           e0 = e1; e1 = e2;
           a = an; b = bn; cb = cbn;
         }
