@@ -379,11 +379,13 @@ constexpr int MB_DUMMY = WAVE;                 // LDS slot of the all-zero recor
 // 4x4 block has half of its pixels above the alpha threshold (an 8x8 pair: a quarter), so the walk needs 0.64x the steps
 // (tools/sim_bwd_lists.py) at the same cost per step.
 // With sixteen banks the same instance is met by several banks in the same step all the time, so the banks do not add
-// into a shared row: the fold over the bank's four lanes goes to a slot of its own, [list][list position], and after the
-// walk the staging lane of every instance sums its slots in mini-block order (float; a fixed order per instance, so the
-// row does not depend on what else shares the round).  Slots exist for MB_WIN list positions; a round in which a list is
-// longer is done in passes: a pass takes the instances from the back for which every list still fits
-// (an instance's pairs are never split over passes).
+// into a shared row: the fold over the bank's four lanes goes to an LDS slot of the pair's own, and after the walk the
+// staging lane of every instance sums its slots in mini-block order (float; a fixed order per instance, so the row does
+// not depend on what else shares the round).  Slots are handed out per pass by a prefix sum over the instances' pair
+// counts (an instance's slots are contiguous); there are DYN_CAP of them and MB_WIN positions per list: a round that
+// needs more is done in passes, a pass taking the instances from the back for which everything still fits (an
+// instance's pairs are never split over passes).  13.3 KB of LDS per wave: three waves per SIMD, which the kernel needs
+// (profiles/r03/ab_render_bwd_occupancy_mb16.txt, ab_bwd_mb16_dynamic_slots.txt).
 // ------------------------------------------------------------------------------------------------------------------
 #ifdef BWD_PROFILE
 // variant build only (tools/bwd_profile.py): shader-clock cycles per section, summed over all waves
@@ -397,16 +399,18 @@ __device__ unsigned long long g_bwd_prof[8];
 #define PROF_CNT(k, n)
 #endif
 constexpr int MB_WIN = 26;                   // list positions a pass can hold
-constexpr int MB_ROW = MB_WIN + 1;           // slot row: [0] stays zero (what an instance reads for a list it is not in), then the
-                                             // positions; 108- / 27-word rows put the sixteen banks' slot writes into distinct LDS banks
 constexpr int MB_LIST = MB_WIN + 4;          // list row: [0] takes the writes of the lanes that are not in the list, then the
                                              // entries, two entries of read-ahead: 60 bytes
+constexpr int DYN_CAP = 253;                 // pairs a pass can hold: slot index and record index share a 16-bit list entry,
+                                             // a byte each
 struct MbLds {
   struct Rec { float4 A, B; float C; float pad[3]; } R[WAVE + 1];      // one 48-byte record: one address per list entry
   __attribute__((aligned(16))) uint16_t list[16][MB_LIST];
-  float4 s0[16][MB_ROW];      // sums 0..3 of the pair at [list][1 + position]
-  float4 s1[16][MB_ROW];      // sums 4..7
-  float s2[16][MB_ROW];       // sum 8
+  // slots handed out per pass by a prefix sum over the instances' pair counts: [0] stays zero, 1 .. DYN_CAP are the pairs of
+  // the pass (an instance's slots are contiguous, in mini-block order), DYN_CAP + 1 takes what the dummy steps write
+  float4 s0[DYN_CAP + 2];
+  float4 s1[DYN_CAP + 2];
+  float s2[DYN_CAP + 2];
 #ifdef BWD_LDS_PAD
   char occupancy_probe[BWD_LDS_PAD];
 #endif
@@ -495,10 +499,10 @@ __device__ __forceinline__ void render_bwd_tile_mb16(const int tile, MbLds& L, i
     L.R[MB_DUMMY].B = make_float4(0.f, -__builtin_inff(), 0.f, 0.f);      // log2(opacity) = -inf: alpha = 0
     L.R[MB_DUMMY].C = 0.0f;
   }
-  if (lane < 16) {
-    L.s0[lane][0] = make_float4(0.f, 0.f, 0.f, 0.f);
-    L.s1[lane][0] = make_float4(0.f, 0.f, 0.f, 0.f);
-    L.s2[lane][0] = 0.0f;
+  if (lane == 0) {
+    L.s0[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    L.s1[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    L.s2[0] = 0.0f;
   }
   const uint16_t* mylist = &L.list[mb][1];
 
@@ -537,31 +541,44 @@ __device__ __forceinline__ void render_bwd_tile_mb16(const int tile, MbLds& L, i
     id_next = load_id(lo2, max(lo, 1u));
   }
 
-  // Rows of the most recent pass: every instance sums the slots of its pairs in mini-block order (lanes outside the pass
-  // and lists an instance is not in read the zero slot) and writes one row if it received anything (all-zero sums: no
-  // row, the flag byte stays 0).
+  // Rows of the most recent pass: every instance sums the slots of its pairs, first to last (= in mini-block order; a lane
+  // that has run out of pairs reads the zero slot while others go on) and writes one row if it received anything
+  // (all-zero sums: no row, the flag byte stays 0).
   bool pending = false;
-  uint32_t p_idx[4] = {0u, 0u, 0u, 0u}, p_slot = 0u;
+  uint32_t p_slot = 0u, p_base = 0u, p_cnt = 0u;      // row of this lane's instance, its first slot, number of slots
+  uint32_t p_chunks = 1u;                              // (uniform) groups of four slots the fullest instance of the pass has
   float p_lo2op = 0.0f;
   auto flush_rows = [&]() {
     __builtin_amdgcn_wave_barrier();
     {
       float r9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      // four slots per trip to LDS (twelve reads in flight, then the adds in slot order); p_chunks = how many trips the
+      // instance with the most pairs needs
+      auto chunk = [&](const uint32_t c0) {
+        float4 f[4], g[4];
+        float hh[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const uint32_t at = (p_idx[r] >> (8 * k)) & 0xffu;
-          const float4 f = L.s0[4 * r + k][at], g = L.s1[4 * r + k][at];
-          const float hh = L.s2[4 * r + k][at];
-          r9[0] += f.x; r9[1] += f.y; r9[2] += f.z; r9[3] += f.w;
-          r9[4] += g.x; r9[5] += g.y; r9[6] += g.z; r9[7] += g.w;
-          r9[8] += hh;
+        for (int t = 0; t < 4; ++t) {
+          const uint32_t at = (c0 + t < p_cnt) ? p_base + c0 + t : 0u;
+          f[t] = L.s0[at];
+          g[t] = L.s1[at];
+          hh[t] = L.s2[at];
         }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          r9[0] += f[t].x; r9[1] += f[t].y; r9[2] += f[t].z; r9[3] += f[t].w;
+          r9[4] += g[t].x; r9[5] += g[t].y; r9[6] += g[t].z; r9[7] += g[t].w;
+          r9[8] += hh[t];
+        }
+      };
+      chunk(0u);
+      if (p_chunks > 1u) chunk(4u);
+      if (p_chunks > 2u) chunk(8u);
+      if (p_chunks > 3u) chunk(12u);
       uint32_t bits = 0u;
 #pragma unroll
       for (int t = 0; t < 9; ++t) bits |= __float_as_uint(r9[t]);
-      const bool nz = (bits << 1) != 0u;      // lanes outside the pass read zero slots only
+      const bool nz = (bits << 1) != 0u;      // lanes outside the pass read nothing
       if (nz) {
         float4* dst = reinterpret_cast<float4*>(rows + p_slot);
         dst[0] = make_float4(r9[0], r9[1], -0.5f * r9[2], -r9[3]);                                   // Mx, My, dcxx, dcxy
@@ -625,7 +642,11 @@ __device__ __forceinline__ void render_bwd_tile_mb16(const int tile, MbLds& L, i
         sfx[r] = tot - incl + own[r];
         over |= sfx[r] + (uint32_t)(127 - MB_WIN) * 0x01010101u;      // bit 7 of a byte: that list is past the window here
       }
-      const bool inA = rem && (over & 0x80808080u) == 0u;             // the top remaining lane always is
+      // slots: the pairs of the remaining instances above this one, plus its own, have to fit
+      const uint32_t cnt = (uint32_t)__popc(mr);
+      const uint32_t cincl = wave_incl_scan_dpp(cnt);
+      const uint32_t above = (uint32_t)__builtin_amdgcn_readlane((int)cincl, WAVE - 1) - cincl;
+      const bool inA = rem && (over & 0x80808080u) == 0u && above + cnt <= (uint32_t)DYN_CAP;
       const unsigned long long balA = __builtin_amdgcn_ballot_w64(inA);
       // list lengths of the pass = the counters at its lowest lane; the longest one sets the number of steps
       uint32_t nmax;
@@ -642,14 +663,13 @@ __device__ __forceinline__ void render_bwd_tile_mb16(const int tile, MbLds& L, i
         nmax = (uint32_t)__builtin_amdgcn_readlane((int)len, 0);
       }
       // idx[r], byte k: 1 + this instance's position in list 4 r + k, 0 for a list it is not in (or not in this pass): the
-      // row index of its list entry and of its slot -- index 0 is the junk entry / the zero slot, so neither the list
-      // build nor the sums below need a branch or a predicate
+      // row index of its list entry -- index 0 is the junk entry, so the list build needs no branch or predicate
       uint32_t idx[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) idx[r] = inA ? (sfx[r] & (own[r] * 0xffu)) : 0u;
       __builtin_amdgcn_wave_barrier();
       {   // pad the lists with the dummy record
-        const uint32_t dd = (uint32_t)MB_DUMMY * 0x10001u;
+        const uint32_t dd = ((uint32_t)MB_DUMMY | ((uint32_t)(DYN_CAP + 1) << 8)) * 0x10001u;
         uint4* l4 = reinterpret_cast<uint4*>(&L.list[0][0]);
         if (lane < 16 * MB_LIST * 2 / 16) l4[lane] = make_uint4(dd, dd, dd, dd);
       }
@@ -657,20 +677,24 @@ __device__ __forceinline__ void render_bwd_tile_mb16(const int tile, MbLds& L, i
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) L.list[4 * r + k][(idx[r] >> (8 * k)) & 0xffu] = (uint16_t)lane;
+        for (int k = 0; k < 4; ++k) {
+          // entry: record index in the low byte, slot in the high byte (first slot + rank of the mini-block in the mask)
+          const uint32_t sl = above + 1u + (uint32_t)__popc(m & ((1u << (4 * r + k)) - 1u));
+          L.list[4 * r + k][(idx[r] >> (8 * k)) & 0xffu] = (uint16_t)((sl << 8) | (uint32_t)lane);
+        }
       __builtin_amdgcn_wave_barrier();
       // two copies of the walk: the 0.99 clamp costs an instruction per pixel and almost no round needs it
       auto walk = [&](auto clamped_c) {
         constexpr bool CLAMPED = decltype(clamped_c)::value;
         auto fetch = [&](uint32_t e, float4& a, float4& b, float& cb) {
-          const char* rp = reinterpret_cast<const char*>(L.R) + 48u * e;
+          const char* rp = reinterpret_cast<const char*>(L.R) + 48u * (e & 0xffu);
           a = *reinterpret_cast<const float4*>(rp);
           b = *reinterpret_cast<const float4*>(rp + 16);
           cb = *reinterpret_cast<const float*>(rp + 32);
         };
         // one (instance, mini-block) pair per bank: list entry e0 (its record: a, b, cb), list position i
         auto step = [&](const float4 a, const float4 b, const float cb, const uint32_t e0, const uint32_t i) {
-          const uint32_t pos1 = cur_lo + e0 + 1u;
+          const uint32_t pos1 = cur_lo + (e0 & 0xffu) + 1u;
           // per-lane partial sums over the quad; un-scaled forms (constants applied to the row):
           //   v0 = sum h dx, v1 = sum h dy (first moments), v2 = sum h dx^2, v3 = sum h dx dy, v4 = sum h dy^2 with
           //   h = opacity*G*dL_dalpha;  v5 = sum h (= opacity * dL_dopacity);  v6..8 = sum alpha*T*dL_dpix
@@ -718,9 +742,9 @@ __device__ __forceinline__ void render_bwd_tile_mb16(const int tile, MbLds& L, i
           // values and all four write them (same address, same data): no EXEC change, the step stays one basic block
           // (-3 %, profiles/r03/ab_bwd_mb16_step.txt; two steps per iteration in one block: no better, the odd lengths cost
           // a step)
-          L.s0[mb][i + 1] = make_float4(v[0], v[1], v[2], v[3]);
-          L.s1[mb][i + 1] = make_float4(v[4], v[5], v[6], v[7]);
-          L.s2[mb][i + 1] = v[8];
+          L.s0[e0 >> 8] = make_float4(v[0], v[1], v[2], v[3]);
+          L.s1[e0 >> 8] = make_float4(v[4], v[5], v[6], v[7]);
+          L.s2[e0 >> 8] = v[8];
         };
         uint32_t e0 = mylist[0], e1 = mylist[1];
         float4 a, b, an, bn;
@@ -747,10 +771,12 @@ __device__ __forceinline__ void render_bwd_tile_mb16(const int tile, MbLds& L, i
       // the rows of this pass are summed and written when its slots are about to be reused (flush_rows): the stores
       // are then in flight during a walk instead of in front of the next round's wait for its records
       pending = true;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) p_idx[r] = idx[r];
       p_slot = slot;
       p_lo2op = lo2op;
+      p_base = above + 1u;
+      p_cnt = inA ? cnt : 0u;
+      p_chunks = 1u + (__builtin_amdgcn_ballot_w64(p_cnt > 4u) != 0ull ? 1u : 0u) + (__builtin_amdgcn_ballot_w64(p_cnt > 8u) != 0ull ? 1u : 0u) +
+                 (__builtin_amdgcn_ballot_w64(p_cnt > 12u) != 0ull ? 1u : 0u);
       remaining &= ~balA;
     }
   }
@@ -765,9 +791,8 @@ __device__ __forceinline__ void render_bwd_tile_mb16(const int tile, MbLds& L, i
 #endif
 }
 
-// 19 KB of LDS per wave: two blocks of four waves per CU.  The kernel is bound by vector instruction issue and two waves
-// per SIMD keep it issuing (profiles/r03/ab_render_bwd_occupancy.txt)
-constexpr int BWD_WAVES = 2;
+// 13.3 KB of LDS per wave: three blocks of four waves per CU, three waves per SIMD
+constexpr int BWD_WAVES = 3;
 __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE, BWD_WAVES) void render_bwd_kernel(int W, int H, int grid_x, int num_tiles,
                                                           const uint32_t* __restrict__ tile_order,
                                                           const uint2* __restrict__ ranges,
