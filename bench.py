@@ -133,16 +133,26 @@ def cpu_baseline(cfg, seed, budget_tiles=1024, bwd_tiles=96):
     pre = preprocess_ref(leaves[0], torch.sigmoid(leaves[5]), st, shs=torch.cat((leaves[1], leaves[2]), dim=1),
                          scales=torch.exp(leaves[3]), rotations=torch.nn.functional.normalize(leaves[4]))
     b1 = time.perf_counter()
-    col = render_tiles_ref(pre, plist, ranges, st, tiles=tiles_b)[0]
-    b2 = time.perf_counter()
-    loss = (col - target).abs().mean()
     # backward in two legs so that only the tile-dependent one is extrapolated: compositing (down to the per-Gaussian
-    # screen-space quantities), then preprocess (every Gaussian, independent of the tile sample)
+    # screen-space quantities), then preprocess (every Gaussian, independent of the tile sample).  The compositing leg is
+    # timed twice and the faster pass kept: its autograd backward scatters into V-sized tensors once per tile and has
+    # been seen to take 1.3 s or 15 s for the same 96 tiles depending on what else the host is doing (x85 extrapolated)
     mids = [pre[k] for k in ("v_xy", "v_conic", "v_opacity", "v_rgb") if pre[k].requires_grad]
-    g_mid = torch.autograd.grad(loss, mids)
-    b3 = time.perf_counter()
+    best = None
+    for _ in range(2):
+        c0 = time.perf_counter()
+        col = render_tiles_ref(pre, plist, ranges, st, tiles=tiles_b)[0]
+        c1 = time.perf_counter()
+        loss = (col - target).abs().mean()
+        g_mid = torch.autograd.grad(loss, mids)
+        c2 = time.perf_counter()
+        if best is None or (c2 - c0) < (best[1] - best[0]) + (best[2] - best[1]):
+            best = (c0, c1, c2)
+    b2 = b1 + (best[1] - best[0])
+    b3 = b2 + (best[2] - best[1])
+    b3_wall = time.perf_counter()
     torch.autograd.backward(mids, g_mid)
-    b4 = time.perf_counter()
+    b4 = b3 + (time.perf_counter() - b3_wall)
     scale_b = n_tiles / len(tiles_b)
     step_s = (b1 - b0) + (t2 - t1) + ((b2 - b1) + (b3 - b2)) * scale_b + (b4 - b3)
     return {
