@@ -174,7 +174,10 @@ int gsr_event_destroy(void* event);
 int gsr_event_wait(void* event);                 /* blocks the calling thread until the event has completed */
 int gsr_event_query(void* event, int32_t* done); /* *done = 1 when completed; never blocks */
 
-/* ---- backward ------------------------------------------------------------------------- */
+/* ---- backward -------------------------------------------------------------------------
+ * geom_ws, bin_ws and img_ws as the forward of the SAME frame left them: besides the sorted point list, bin_ws holds the
+ * 16-bit mini-block reach mask of every instance, which the forward's compositing stores in list order (in the tile
+ * sort's spare payload buffer) when p->forward_only is 0 and the backward's compositing reads instead of re-deriving. */
 int gsr_backward(const GsrParams* p, const int32_t* radii, const void* geom_ws, const void* bin_ws,
                  const void* img_ws, uint32_t num_rendered, uint32_t num_visible,
                  const float* dL_dout_color /* [3,H,W] */,
