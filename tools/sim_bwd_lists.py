@@ -1,11 +1,14 @@
 """Offline estimate (CPU, oracle preprocess) of the step counts of list-driven backward walks: rounds of 64 instances
 from the back of a tile's list, the round costs max(list lengths) steps.  Compares four 8x8 sub-block lists (the round-3
-kernel) with sixteen 4x4 mini-block lists.  Usage: python tools/sim_bwd_lists.py [C4|C3|C2] [tiles]"""
+kernel) with sixteen 4x4 mini-block lists.  Usage: python tools/sim_bwd_lists.py [C4|C3|C2] [tiles] [instances per round]"""
 import sys, numpy as np, torch
 sys.path.insert(0, ".")
 from mvs_gaussian_splatting_amd.synthetic import CONFIGS, make_scene
 import math
 from oracle import rasterizer_ref as R
+
+ROUND = int(sys.argv[3]) if len(sys.argv) > 3 else 64      # instances per round
+
 
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "C4"
@@ -40,8 +43,8 @@ def main():
         m4, m16, ok = m4[keep], m16[keep], ok[keep]
         n = m4.shape[0]
         tot["inst"] += n
-        for hi in range(n, 0, -64):
-            lo = max(0, hi - 64)
+        for hi in range(n, 0, -ROUND):
+            lo = max(0, hi - ROUND)
             tot["rounds"] += 1
             tot["s4"] += m4[lo:hi].sum(0).max(); tot["p4"] += m4[lo:hi].sum()
             tot["s16"] += m16[lo:hi].sum(0).max(); tot["p16"] += m16[lo:hi].sum()
