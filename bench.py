@@ -50,10 +50,10 @@ def bytes_really_moved(P, M, V, R, W, H):
     lower bound of the rows read: an on-screen centre whose footprint rounds to zero tiles has its row read too).
     Backward: every Gaussian gets its gradient rows written (56 + 12 M bytes: the operator returns dense tensors) and
     its radius read; a visible one also reads its record, slot, position / scale / rotation, SH row (for d rgb / d dir)
-    and its 49-byte instance rows."""
+    and its 37-byte instance rows (36-byte row + flag byte)."""
     return {
         "preprocess_fwd": 44 * P + (12 * M + 75) * V,
-        "preprocess_bwd": (56 + 12 * M + 4) * P + (64 + 4 + 40 + 12 * M) * V + 49 * R,
+        "preprocess_bwd": (56 + 12 * M + 4) * P + (64 + 4 + 40 + 12 * M) * V + 37 * R,
     }
 
 

@@ -985,7 +985,6 @@ __global__ __launch_bounds__(256) void sum_big_rows_kernel(const uint32_t* __res
       GradRow t;
       t.dmx = acc[0]; t.dmy = acc[1]; t.dcxx = acc[2]; t.dcxy = acc[3]; t.dcyy = acc[4];
       t.dop = acc[5]; t.dr = acc[6]; t.dg = acc[7]; t.db = acc[8];
-      t.pad0 = t.pad1 = t.pad2 = 0.f;
       rows[slot0] = t;
       row_flags[slot0] = hit ? 1 : 0;
     }

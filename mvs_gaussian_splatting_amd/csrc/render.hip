@@ -580,10 +580,11 @@ __device__ __forceinline__ void render_bwd_tile_mb16(const int tile, MbLds& L, i
       for (int t = 0; t < 9; ++t) bits |= __float_as_uint(r9[t]);
       const bool nz = (bits << 1) != 0u;      // lanes outside the pass read nothing
       if (nz) {
-        float4* dst = reinterpret_cast<float4*>(rows + p_slot);
-        dst[0] = make_float4(r9[0], r9[1], -0.5f * r9[2], -r9[3]);                                   // Mx, My, dcxx, dcxy
-        dst[1] = make_float4(-0.5f * r9[4], r9[5] * __builtin_amdgcn_exp2f(-p_lo2op), r9[6], r9[7]);   // dcyy, dop, dr, dg
-        dst[2] = make_float4(r9[8], 0.f, 0.f, 0.f);                                                  // db
+        GradRow t;
+        t.dmx = r9[0]; t.dmy = r9[1]; t.dcxx = -0.5f * r9[2]; t.dcxy = -r9[3];
+        t.dcyy = -0.5f * r9[4]; t.dop = r9[5] * __builtin_amdgcn_exp2f(-p_lo2op); t.dr = r9[6]; t.dg = r9[7];
+        t.db = r9[8];
+        rows[p_slot] = t;
         row_flags[p_slot] = 1;
       }
     }
