@@ -417,9 +417,10 @@ struct MbLds {
 };
 static_assert((16 * MB_LIST * 2) % 16 == 0 && 16 * MB_LIST * 2 / 16 <= WAVE, "the list block is padded by one 16-byte store per lane");
 
-// sums of nine values over the four lanes of every DPP bank (all four lanes get them): 18 operations
+// sums of nine values over the four lanes of every DPP bank (all four lanes get them): 18 operations.  volatile: a DPP
+// operand is read from OTHER lanes, the statement must stay where the whole wave executes it
 __device__ __forceinline__ void quad_fold9(float (&v)[9]) {
-  asm(
+  asm volatile(
       "s_nop 1\n\t"
       "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
       "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"

@@ -18,9 +18,13 @@ badly conditioned that float32 itself is further off fails instead of silently o
 printed for every tensor.  (Worst bars seen on the round-2 suite: means2D 2.9e-5, xyz 1.1e-4.)
 
 The masked pixels are not left unchecked: compare_grads_unmasked() runs the same scene with EVERY pixel in the loss
-(plain L1) against float64 at the loose bar of round 1 (2e-3 max-norm relative) and requires finite gradients -- a
-forward / backward decision mismatch on a threshold pixel (different clamp scope, a sub-block cut-off, a recomputed
-T / (1 - alpha)) shows up there as an error of the order of the pixel's whole contribution.
+(plain L1) against float64 and requires finite gradients within 2e-3 (max-norm relative) when the scene has no
+threshold-fragile pixel, 2e-2 when it has: a float32 and a float64 evaluation may take different decisions on such a
+pixel, and each flip moves a gradient by the pixel's whole contribution (a soak over fuzz seeds 72..179 saw up to
+6.3e-3 with 19 fragile pixels in the loss, 3.9e-3 with two; the masked comparison of the same scenes stayed at the
+float32 oracle's own error).  What that run cannot tell apart from such a flip -- the backward taking a different
+decision than the FORWARD on a threshold pixel (clamp scope, list cut-off, last contributor) -- is checked exactly and
+without any oracle by test_gpu_parity.py::test_backward_takes_the_forwards_decisions_pixel_by_pixel.
 """
 import torch
 
@@ -28,7 +32,8 @@ MARGIN = 1e-4
 SIGN_EPS = 1e-5
 TOL = 1e-5
 ESCAPE_CAP = 2e-4       # the conditioning escape (2 x the float32 oracle's own error) never opens the bar beyond this
-UNMASKED_TOL = 2e-3     # every pixel in the loss, threshold-fragile ones included
+UNMASKED_TOL = 2e-3             # every pixel in the loss, none of them threshold-fragile
+UNMASKED_TOL_FRAGILE = 2e-2     # threshold-fragile pixels in the loss: float32 / float64 decision flips are legitimate
 
 RAW = ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")
 
@@ -112,9 +117,10 @@ def compare_grads(got, ref, ref32=None, label=""):
 
 
 def compare_grads_unmasked(got, ref, n_fragile, label=""):
-    """Every pixel in the loss (weights all one): finite, and within UNMASKED_TOL of float64 per tensor (max-norm
-    relative).  Prints the count of threshold-fragile pixels the masked comparison leaves out."""
+    """Every pixel in the loss (weights all one): finite, and within UNMASKED_TOL (UNMASKED_TOL_FRAGILE when
+    threshold-fragile pixels carry weight) of float64 per tensor, max-norm relative."""
     rows, bad = [], {}
+    tol = UNMASKED_TOL_FRAGILE if n_fragile > 0 else UNMASKED_TOL
     for k, r in ref.items():
         if r.numel() == 0:
             continue
@@ -126,7 +132,7 @@ def compare_grads_unmasked(got, ref, n_fragile, label=""):
             continue
         e = float((g - r).abs().max()) / scale
         rows.append(f"{k}: {e:.2e}")
-        if e > UNMASKED_TOL:
+        if e > tol:
             bad[k] = e
     print(f"[grad parity, unmasked, {n_fragile} fragile pixels in the loss] {label}: " + "; ".join(rows))
-    assert not bad, f"{label}: unmasked gradient error above {UNMASKED_TOL}: {bad}"
+    assert not bad, f"{label}: unmasked gradient error above {tol}: {bad}"

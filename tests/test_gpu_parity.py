@@ -622,6 +622,66 @@ def test_fuzz_random_small_scenes_forward_and_backward(gpu_device, seed):
                         f"fuzz seed={seed} " + str(dict(W=W, H=H, deg=deg, P=P, scale=round(scale, 4))))
 
 
+def _fuzz_scene(seed):
+    """The configuration test_fuzz_random_small_scenes_forward_and_backward draws for `seed` (same generator calls)."""
+    from mvs_gaussian_splatting_amd.synthetic import SceneConfig, make_scene
+    rng = np.random.default_rng(1000 + seed)
+    W, H = int(rng.integers(17, 260)), int(rng.integers(17, 200))
+    deg = int(rng.integers(0, 4))
+    P = int(rng.integers(50, 2500))
+    f = float(rng.uniform(40.0, 260.0))
+    scale = float(np.exp(rng.uniform(np.log(0.01), np.log(0.4))))
+    rng.choice([1.0, 1.0, 0.6, 1.7]); rng.integers(0, 3)
+    cfg = SceneConfig("fuzz", P, deg, W, H, f, f * float(rng.uniform(0.8, 1.25)), math.log(scale))
+    model, cam, _, target = make_scene(cfg, seed=seed, view=int(rng.integers(0, 8)))
+    model._opacity += float(rng.uniform(-2.0, 3.0))
+    return model, cam
+
+
+@pytest.mark.parametrize("seed", [0, 3, 83, 85, 106, 111, 131, 139])
+def test_backward_takes_the_forwards_decisions_pixel_by_pixel(gpu_device, seed):
+    """Exact, oracle-free check that the backward composites what the forward composited -- on the threshold-fragile
+    pixels in particular (the ones the masked gradient comparison gives no weight and on which float32 and float64
+    legitimately disagree).  With precomputed colours and a black background the image is linear in the colours,
+    C(p) = sum_i w_i(p) c_i, and the backward of dL/dpix = (1, 1, 1) at ONE pixel p returns dL/dc_i = w_i(p): so
+    sum_i <dL/dc_i, c_i> must reproduce the forward's own sum_ch C_ch(p) to float32 rounding.  A pair the forward blended
+    and the backward skipped (or the reverse: a different alpha >= 1/255 decision, clamp scope, last contributor, list
+    cut-off) is missing from the sum with its whole weight: at least T / 255 of the colour.  Seeds 83 .. 139 are the fuzz
+    configurations whose unmasked gradients differ most from float64 (profiles/r03/fuzz_seeds_72_180.log)."""
+    from gpu_util import product_settings
+    from mvs_gaussian_splatting_amd import GaussianRasterizer
+    from oracle import rasterize_ref
+    dev = gpu_device
+    model, cam = _fuzz_scene(seed)
+    bg = torch.zeros(3)
+    P = model.get_xyz.shape[0]
+    colors = torch.rand(P, 3, generator=torch.Generator().manual_seed(seed)) * 0.9 + 0.1
+    st_o = make_settings(cam, bg, 0)
+    _, _, aux = rasterize_ref(model.get_xyz, None, model.get_opacity, st_o, colors_precomp=colors,
+                              scales=model.get_scaling, rotations=model.get_rotation, want_aux=True, want_margin=True)
+    H, W = cam.image_height, cam.image_width
+    fragile = torch.nonzero(aux["margin"] <= 1e-4)[:24].tolist()
+    rng = np.random.default_rng(seed)
+    pixels = fragile + [[int(rng.integers(0, H)), int(rng.integers(0, W))] for _ in range(8)]
+    st = product_settings(cam, bg, 0, dev)
+    xyz, op = model.get_xyz.to(dev), model.get_opacity.to(dev)
+    sc, rot = model.get_scaling.to(dev), model.get_rotation.to(dev)
+    worst = 0.0
+    for y, x in pixels:
+        c = colors.to(dev).requires_grad_(True)
+        col, _ = GaussianRasterizer(st)(means3D=xyz, means2D=torch.zeros_like(xyz), opacities=op, colors_precomp=c,
+                                        scales=sc, rotations=rot)
+        dL = torch.zeros_like(col)
+        dL[:, y, x] = 1.0
+        col.backward(dL)
+        lhs = float((c.grad.double() * c.detach().double()).sum())
+        rhs = float(col[:, y, x].detach().double().sum())
+        err = abs(lhs - rhs) / max(abs(rhs), 1e-2)
+        worst = max(worst, err)
+        assert err <= 1e-5, (seed, (y, x), lhs, rhs, "fragile" if [y, x] in fragile else "random")
+    print(f"[fwd/bwd decisions] fuzz seed={seed}: {len(fragile)} fragile + 8 random pixels, worst relative mismatch {worst:.1e}")
+
+
 def test_render_host_modes_and_leaf_reuse(gpu_device):
     """render() under no_grad / inference_mode, and two frames whose screen-space leaves alias the cached zeros:
     each backward fills its own .grad."""

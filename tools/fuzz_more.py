@@ -13,14 +13,23 @@ import test_gpu_parity as t  # noqa: E402
 
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 dev = torch.device("cuda:0")
-bad = []
+bad, skipped = [], []
 for seed in range(lo, hi):
     try:
         t.test_fuzz_random_small_scenes_forward_and_backward(dev, seed)
         print("seed", seed, "ok", flush=True)
+    except AssertionError as ex:
+        if "too ill-conditioned to test" in str(ex):      # tests/grad_util.py ESCAPE_CAP: the float32 oracle itself is > 1e-4
+            skipped.append(seed)                           # off float64 on this scene; nothing can be concluded from it
+            print("seed", seed, "SKIPPED (ill-conditioned scene):", str(ex)[:300], flush=True)
+        else:
+            bad.append(seed)
+            print("seed", seed, "FAILED", flush=True)
+            traceback.print_exc()
     except Exception:      # noqa: BLE001
         bad.append(seed)
         print("seed", seed, "FAILED", flush=True)
         traceback.print_exc()
+print("skipped (ill-conditioned):", skipped)
 print("failed seeds:", bad)
 sys.exit(1 if bad else 0)
