@@ -376,6 +376,38 @@ def main():
         pipe.fuse_activations = True
         pipe.fuse_densify_stats = fuse_stats_was
 
+    # Not part of `value`: the forward of a FIXED model with three frames in flight on three streams (MultiStreamRenderer:
+    # the reference's render.py situation, a trained model and a list of cameras).  A frame is HBM-bound for two thirds
+    # and VALU-bound for the last, so frames on different streams overlap the two.
+    multi = None
+    if world == 1:
+        try:
+            from mvs_gaussian_splatting_amd.graphed import MultiStreamRenderer
+            with torch.no_grad():
+                mr = MultiStreamRenderer(model, pipe, bg, streams=3)
+                views = [cam] * 48
+                for _ in mr.render_views(views[:12]):
+                    pass
+                mr.check()
+                dts = []
+                for _rep in range(3):
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    for _ in mr.render_views(views):
+                        pass
+                    mr.check()
+                    dts.append((time.perf_counter() - t0) / len(views))
+                dt = min(dts)
+                print(f"[bench] multi-stream forward, 3 x {len(views)} frames: " + ", ".join(f"{x * 1e3:.3f}" for x in dts) +
+                      " ms per frame", file=sys.stderr, flush=True)
+                del mr
+            multi = {"streams": 3, "frames": len(views), "ms_per_frame": round(dt * 1e3, 3),
+                     "mpixels_per_s": round(W * H / dt / 1e6, 1),
+                     "note": "fixed model, forward only, frames of the same view in flight on three streams; images "
+                             "bit-identical to render() (tests/test_gpu_graphed.py); NOT the headline value"}
+        except Exception as ex:  # noqa: BLE001
+            multi = {"streams": 3, "ms_per_frame": None, "note": f"failed: {ex!r}"}
+
     # instances of this rank's view: read back from the stage the operator itself ran
     from mvs_gaussian_splatting_amd.rasterizer import frame_counts
     R = int(frame_counts(pkg["render"])[0]) if pkg["render"].grad_fn is not None else 0
@@ -531,6 +563,8 @@ def main():
         }
         if unfused:
             line.update(unfused)
+        if multi:
+            line["fwd_multi_stream"] = multi
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(cfg, args.seed)

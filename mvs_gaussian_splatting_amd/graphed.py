@@ -181,3 +181,75 @@ class GraphedRenderer:
                     need = f.last_counts[0]
                     self._capture(f, need)
                     raise _lib.GsrError(f"a graphed frame overflowed its binning capacity ({need} instances); graph rebuilt")
+
+
+class MultiStreamRenderer:
+    """Forward-only rendering of a fixed model with several frames in flight, one per HIP stream.
+
+    A frame is bound by HBM bandwidth for its first two thirds (preprocess, binning) and by vector instruction issue for
+    the last (compositing), so two frames on two streams overlap the one with the other: 1.15x the frames per second at
+    6 M Gaussians / 1080p, 1.4x at 1 M, 1.8x at 100 k / 800x800 (``profiles/r03/multi_stream.txt``).  Frames are
+    independent -- the model does not change -- which is the situation of the reference's ``render.py:32-40`` (a trained
+    model, a list of cameras).  Every stream has its own ``GraphedRenderer`` (workspaces, static buffers, captured
+    graph); the parameters are shared, read-only.
+
+        mr = MultiStreamRenderer(gaussians, pipe, background, streams=2)
+        for i, out in mr.render_views(cameras):        # in order; `out` is valid until `streams` more frames were issued
+            save(out["render"])                        # (work issued on the current stream sees the finished frame)
+        mr.check()
+
+    ``render_views`` keeps ``streams`` frames in flight and hands each one over once the CURRENT stream has been made to
+    wait for it; whatever the caller enqueues on the current stream afterwards (a copy to the host, an encoder) runs
+    after the frame and before the lane's buffers are reused.
+    """
+
+    def __init__(self, pc, pipe, bg_color: torch.Tensor, scaling_modifier: float = 1.0, streams: int = 2):
+        if streams < 1:
+            raise ValueError("streams must be >= 1")
+        self.dev = pc.get_xyz.device
+        if not pc.get_xyz.is_cuda:
+            raise _lib.GsrError("MultiStreamRenderer needs the model on a ROCm GPU (no CPU path)")
+        self.streams = [torch.cuda.Stream(self.dev) for _ in range(streams)]
+        self.lanes = [GraphedRenderer(pc, pipe, bg_color, scaling_modifier) for _ in range(streams)]
+        self.done = [torch.cuda.Event() for _ in range(streams)]
+        self.released = [None] * streams      # event on the consumer's stream after which a lane's buffers may be reused
+        self.issued = 0
+
+    def _issue(self, cam):
+        k = self.issued % len(self.lanes)
+        s = self.streams[k]
+        cur = torch.cuda.current_stream(self.dev)
+        s.wait_stream(cur)                     # the camera (and, the first time, the parameters) may come from there
+        if self.released[k] is not None:
+            s.wait_event(self.released[k])     # the consumer of this lane's previous frame has read it
+        with torch.cuda.stream(s):
+            out = self.lanes[k].render(cam)
+            self.done[k].record(s)
+        self.issued += 1
+        return k, out
+
+    def render_views(self, cameras):
+        """Generator of (index, result) in camera order with ``len(self.streams)`` frames in flight."""
+        cameras = list(cameras)
+        n = len(self.lanes)
+        inflight = []
+        nxt = 0
+        with torch.cuda.device(self.dev):
+            for i in range(len(cameras)):
+                while nxt < len(cameras) and len(inflight) < n:
+                    inflight.append(self._issue(cameras[nxt]))
+                    nxt += 1
+                k, out = inflight.pop(0)
+                cur = torch.cuda.current_stream(self.dev)
+                cur.wait_event(self.done[k])
+                yield i, out
+                ev = torch.cuda.Event()
+                ev.record(cur)                 # whatever the consumer enqueued on the current stream for this frame
+                self.released[k] = ev
+
+    def check(self) -> None:
+        """Block until every issued frame has completed and been checked against its capacity (see GraphedRenderer)."""
+        for s in self.streams:
+            s.synchronize()
+        for lane in self.lanes:
+            lane.check()

@@ -74,3 +74,28 @@ def test_graphed_overflow_is_detected_and_repaired(gpu_device):
             gr.render(cams[0])
         assert torch.equal(gr.render(cams[2], verify=True)["render"], render(cams[2], model, PipelineParams(), bg)["render"])
         gr.check()
+
+
+@pytest.mark.parametrize("streams", [1, 2, 3])
+def test_multi_stream_frames_equal_eager_frames(gpu_device, streams):
+    """Several frames in flight, one per stream (own workspaces, shared parameters): every image the generator hands over
+    is the eager render() of its camera, bit for bit, also when the consumer reads it on the current stream only after
+    further frames have been issued, and when a lane's buffers are reused many times."""
+    from mvs_gaussian_splatting_amd import render
+    from mvs_gaussian_splatting_amd.graphed import MultiStreamRenderer
+    from mvs_gaussian_splatting_amd.synthetic import PipelineParams
+    dev = gpu_device
+    model, _, _, _ = small_scene(P=20000, sh_degree=2, width=304, height=176, scale=0.03)
+    model.to(dev)
+    bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
+    cams = _cams(dev, 8) * 3
+    mr = MultiStreamRenderer(model, PipelineParams(), bg, streams=streams)
+    kept = []
+    with torch.no_grad():
+        for i, out in mr.render_views(cams):
+            kept.append(out["render"].clone())          # a copy enqueued on the current stream: sees the finished frame
+        mr.check()
+        assert len(kept) == len(cams)
+        for cam, got in zip(cams, kept):
+            assert torch.equal(got, render(cam, model, PipelineParams(), bg)["render"])
+    assert sum(next(iter(l.formats.values())).frames for l in mr.lanes) == len(cams)
