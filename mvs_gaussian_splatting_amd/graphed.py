@@ -187,8 +187,10 @@ class MultiStreamRenderer:
     """Forward-only rendering of a fixed model with several frames in flight, one per HIP stream.
 
     A frame is bound by HBM bandwidth for its first two thirds (preprocess, binning) and by vector instruction issue for
-    the last (compositing), so two frames on two streams overlap the one with the other: 1.15x the frames per second at
-    6 M Gaussians / 1080p, 1.4x at 1 M, 1.8x at 100 k / 800x800 (``profiles/r03/multi_stream.txt``).  Frames are
+    the last (compositing), and the ~27 launches of a small frame leave the GPU waiting: frames on different streams fill
+    each other's gaps.  With three streams 1.2x the frames per second at 6 M Gaussians / 1080p, 1.6x at 1 M, 2.4x at
+    100 k / 800x800 (``profiles/r03/multi_stream.txt``; two streams gain little: frames issued together run in lockstep,
+    HBM-bound phase against HBM-bound phase).  Frames are
     independent -- the model does not change -- which is the situation of the reference's ``render.py:32-40`` (a trained
     model, a list of cameras).  Every stream has its own ``GraphedRenderer`` (workspaces, static buffers, captured
     graph); the parameters are shared, read-only.
@@ -215,11 +217,13 @@ class MultiStreamRenderer:
         self.released = [None] * streams      # event on the consumer's stream after which a lane's buffers may be reused
         self.issued = 0
 
-    def _issue(self, cam):
+    def _issue(self, cam, inputs_ready):
         k = self.issued % len(self.lanes)
         s = self.streams[k]
-        cur = torch.cuda.current_stream(self.dev)
-        s.wait_stream(cur)                     # the camera (and, the first time, the parameters) may come from there
+        # the cameras (and, the first time, the parameters) may have been produced on the caller's stream: wait for the
+        # point at which render_views() was called, not for the stream's tail -- the tail holds the hand-overs of the
+        # frames before this one
+        s.wait_event(inputs_ready)
         if self.released[k] is not None:
             s.wait_event(self.released[k])     # the consumer of this lane's previous frame has read it
         with torch.cuda.stream(s):
@@ -235,9 +239,11 @@ class MultiStreamRenderer:
         inflight = []
         nxt = 0
         with torch.cuda.device(self.dev):
+            inputs_ready = torch.cuda.Event()
+            inputs_ready.record(torch.cuda.current_stream(self.dev))
             for i in range(len(cameras)):
                 while nxt < len(cameras) and len(inflight) < n:
-                    inflight.append(self._issue(cameras[nxt]))
+                    inflight.append(self._issue(cameras[nxt], inputs_ready))
                     nxt += 1
                 k, out = inflight.pop(0)
                 cur = torch.cuda.current_stream(self.dev)
