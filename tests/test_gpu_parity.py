@@ -638,7 +638,7 @@ def _fuzz_scene(seed):
     return model, cam
 
 
-@pytest.mark.parametrize("seed", [0, 3, 83, 85, 106, 111, 131, 139])
+@pytest.mark.parametrize("seed", [0, 3, 83, 85, 106, 111, 131, 139, 283])
 def test_backward_takes_the_forwards_decisions_pixel_by_pixel(gpu_device, seed):
     """Exact, oracle-free check that the backward composites what the forward composited -- on the threshold-fragile
     pixels in particular (the ones the masked gradient comparison gives no weight and on which float32 and float64
@@ -646,8 +646,8 @@ def test_backward_takes_the_forwards_decisions_pixel_by_pixel(gpu_device, seed):
     C(p) = sum_i w_i(p) c_i, and the backward of dL/dpix = (1, 1, 1) at ONE pixel p returns dL/dc_i = w_i(p): so
     sum_i <dL/dc_i, c_i> must reproduce the forward's own sum_ch C_ch(p) to float32 rounding.  A pair the forward blended
     and the backward skipped (or the reverse: a different alpha >= 1/255 decision, clamp scope, last contributor, list
-    cut-off) is missing from the sum with its whole weight: at least T / 255 of the colour.  Seeds 83 .. 139 are the fuzz
-    configurations whose unmasked gradients differ most from float64 (profiles/r03/fuzz_seeds_72_180.log)."""
+    cut-off) is missing from the sum with its whole weight: at least T / 255 of the colour.  Seeds 83 .. 283 are the fuzz
+    configurations whose unmasked gradients differ most from float64 (profiles/r03/fuzz_seeds_72_180.log, fuzz_seeds_180_290.log: up to 9.8e-3 at seed 283)."""
     from gpu_util import product_settings
     from mvs_gaussian_splatting_amd import GaussianRasterizer
     from oracle import rasterize_ref
