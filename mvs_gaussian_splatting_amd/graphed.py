@@ -190,12 +190,12 @@ class MultiStreamRenderer:
     the last (compositing), and the ~27 launches of a small frame leave the GPU waiting: frames on different streams fill
     each other's gaps.  With three streams 1.2x the frames per second at 6 M Gaussians / 1080p, 1.6x at 1 M, 2.4x at
     100 k / 800x800 (``profiles/r03/multi_stream.txt``; two streams gain little: frames issued together run in lockstep,
-    HBM-bound phase against HBM-bound phase).  Frames are
+    HBM-bound phase against HBM-bound phase, and stream priorities meant to stagger them cost more than they give).  Frames are
     independent -- the model does not change -- which is the situation of the reference's ``render.py:32-40`` (a trained
     model, a list of cameras).  Every stream has its own ``GraphedRenderer`` (workspaces, static buffers, captured
     graph); the parameters are shared, read-only.
 
-        mr = MultiStreamRenderer(gaussians, pipe, background, streams=2)
+        mr = MultiStreamRenderer(gaussians, pipe, background, streams=3)
         for i, out in mr.render_views(cameras):        # in order; `out` is valid until `streams` more frames were issued
             save(out["render"])                        # (work issued on the current stream sees the finished frame)
         mr.check()
@@ -205,7 +205,7 @@ class MultiStreamRenderer:
     after the frame and before the lane's buffers are reused.
     """
 
-    def __init__(self, pc, pipe, bg_color: torch.Tensor, scaling_modifier: float = 1.0, streams: int = 2):
+    def __init__(self, pc, pipe, bg_color: torch.Tensor, scaling_modifier: float = 1.0, streams: int = 3):
         if streams < 1:
             raise ValueError("streams must be >= 1")
         self.dev = pc.get_xyz.device
