@@ -331,7 +331,18 @@ def main():
             b.copy_(a)
         e1.record()
         torch.cuda.synchronize(dev)
-        return 10 * 2 * 4 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        rate_copy = 10 * 2 * 4 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        # the runtime's copy is not the fastest way to move bytes on this part: an elementwise KERNEL (one 16-byte access
+        # per lane) streams ~20 % faster (tools/ubench/hbm_stream.hip: 6.2-6.6 TB/s); reported next to it
+        for _ in range(3):
+            torch.add(a, 1.0, out=b)
+        e0.record()
+        for _ in range(10):
+            torch.add(a, 1.0, out=b)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        copy_ceiling.kernel_rate = 10 * 2 * 4 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        return rate_copy
 
     K = args.steps
     # The W warm-up steps above take ~10 ms in all: not long enough for the GPU to leave its idle clocks (per-frame time
@@ -537,6 +548,7 @@ def main():
             "fwd_step_ms_p10_p50_p90": [pct(fwd_steps, 0.1), pct(fwd_steps, 0.5), pct(fwd_steps, 0.9)],
             "train_step_ms_p10_p50_p90": [pct(train_steps, 0.1), pct(train_steps, 0.5), pct(train_steps, 0.9)],
             "hbm_copy_measured_GBs": copy_GBs,
+            "hbm_elementwise_kernel_GBs": round(getattr(copy_ceiling, "kernel_rate", 0.0), 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {P} Gaussians, SH degree {cfg.sh_degree}, {W}x{H}, one view per GPU; "
                                    "value = forward-only steps, ms_per_step = render+L1+backward+densify-stats steps",
