@@ -126,6 +126,14 @@ def test_no_cpu_fallback_exists():
         render(cam, model, PipelineParams(), bg)
     with pytest.raises(_lib.GsrError):
         l1_loss(torch.zeros(3, 4, 4), torch.zeros(3, 4, 4))
+    # the fixed-model helpers too: no graph, no streams, no silent CPU rendering
+    from mvs_gaussian_splatting_amd.graphed import GraphedRenderer, MultiStreamRenderer
+    with pytest.raises(_lib.GsrError, match="no CPU path"):
+        GraphedRenderer(model, PipelineParams(), bg)
+    with pytest.raises(_lib.GsrError, match="no CPU path"):
+        MultiStreamRenderer(model, PipelineParams(), bg)
+    with pytest.raises(ValueError):
+        MultiStreamRenderer(model, PipelineParams(), bg, streams=0)
     # and the product package never imports the oracle
     import mvs_gaussian_splatting_amd as pkg
     pkg_dir = os.path.dirname(pkg.__file__)
