@@ -16,11 +16,14 @@ such format (cameras of one dataset share it).  Training cannot use this class: 
 workspaces, which the next replay overwrites.
 
 Capacity: the first frame of a format runs eagerly (with the count read-back) and sizes the binning workspace at 1.5 x
-its instance count.  Every later frame's real count lands in pinned memory and is compared with the capacity when the
-next frame is requested, in ``check()``, or at once with ``render(..., verify=True)``; an overflowed frame is re-rendered
-with a larger workspace (nothing is lost: the inputs are still there) -- ``verify=True`` therefore always returns a
-complete image, the default returns the previous frame's verdict one call late and raises ``GsrError`` if that frame was
-incomplete.
+its instance count.  Every later frame's real count lands in pinned memory and is compared with the capacity before
+``render()`` returns (``verify=True``, the default: the host waits for that frame); an overflowed frame is re-rendered
+with a larger workspace (nothing is lost: the inputs are still there), so the caller always receives a complete image.
+``verify=False`` is for callers that take the verdict themselves (``MultiStreamRenderer`` does, per frame, before it
+hands the frame over): the verdict then arrives with the next call for the same format or in ``check()``.
+
+The model is FIXED: the operator inputs are snapshotted (cloned) at construction in both input modes; later in-place
+updates of the model's parameters are not seen.
 """
 from __future__ import annotations
 
@@ -46,7 +49,9 @@ class _Format:
 
 
 class GraphedRenderer:
-    def __init__(self, pc, pipe, bg_color: torch.Tensor, scaling_modifier: float = 1.0):
+    def __init__(self, pc, pipe, bg_color: torch.Tensor, scaling_modifier: float = 1.0, share_inputs_with=None):
+        """``share_inputs_with``: another GraphedRenderer of the same model whose input snapshot this one reads too
+        (the lanes of a MultiStreamRenderer: one copy of the parameters, not one per stream)."""
         if not pc.get_xyz.is_cuda:
             raise _lib.GsrError("GraphedRenderer needs the model on a ROCm GPU (no CPU path)")
         if getattr(pipe, "debug", False):
@@ -58,23 +63,25 @@ class GraphedRenderer:
         self.bg = bg_color.detach().to(self.dev, torch.float32).contiguous().clone()
         empty = torch.empty(0, dtype=torch.float32, device=self.dev)
         with torch.no_grad():
-            # the operator inputs, taken ONCE (the model is fixed): raw parameters where the kernels can apply the
-            # activations themselves, the getters' results otherwise
+            # the operator inputs, taken ONCE (the model is fixed) as private copies: raw parameters where the kernels
+            # can apply the activations themselves, the getters' results otherwise
             self.P = int(pc.get_xyz.shape[0])
-            if _can_fuse(pc, pipe, None):
+            snap = lambda t: t.detach().contiguous().clone()  # noqa: E731
+            if share_inputs_with is not None:
+                o = share_inputs_with
+                self.fused, self.inputs, self.act_flags = o.fused, o.inputs, o.act_flags
+            elif _can_fuse(pc, pipe, None):
                 self.fused = True
-                self.inputs = dict(means3D=pc.get_xyz.detach().contiguous(), sh=pc._features_dc.detach().contiguous(),
-                                   colors_precomp=empty, opacities=pc._opacity.detach().contiguous(),
-                                   scales=pc._scaling.detach().contiguous(), rotations=pc._rotation.detach().contiguous(),
+                self.inputs = dict(means3D=snap(pc.get_xyz), sh=snap(pc._features_dc), colors_precomp=empty,
+                                   opacities=snap(pc._opacity), scales=snap(pc._scaling), rotations=snap(pc._rotation),
                                    cov3Ds_precomp=empty,
-                                   sh_rest=pc._features_rest.detach().contiguous() if pc._features_rest.shape[1] else None)
+                                   sh_rest=snap(pc._features_rest) if pc._features_rest.shape[1] else None)
                 self.act_flags = _lib.ACT_SCALE_EXP | _lib.ACT_ROT_NORMALIZE | _lib.ACT_OPACITY_SIGMOID
             else:
                 self.fused = False
-                self.inputs = dict(means3D=pc.get_xyz.detach().contiguous(), sh=pc.get_features.detach().contiguous().clone(),
-                                   colors_precomp=empty, opacities=pc.get_opacity.detach().contiguous().clone(),
-                                   scales=pc.get_scaling.detach().contiguous().clone(),
-                                   rotations=pc.get_rotation.detach().contiguous().clone(), cov3Ds_precomp=empty, sh_rest=None)
+                self.inputs = dict(means3D=snap(pc.get_xyz), sh=snap(pc.get_features), colors_precomp=empty,
+                                   opacities=snap(pc.get_opacity), scales=snap(pc.get_scaling),
+                                   rotations=snap(pc.get_rotation), cov3Ds_precomp=empty, sh_rest=None)
                 self.act_flags = 0
         self.formats: Dict[tuple, _Format] = {}
 
@@ -98,6 +105,7 @@ class GraphedRenderer:
         f.geom = torch.empty(lib.gsr_geom_bytes(P), dtype=torch.uint8, device=dev)
         f.img = torch.empty(lib.gsr_image_bytes(W, H), dtype=torch.uint8, device=dev)
         f.radii = torch.zeros(P, dtype=torch.int32, device=dev)
+        f.visible = torch.zeros(P, dtype=torch.bool, device=dev)      # static: no per-frame allocation on a side stream
         f.color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
         f.binning = None
         self._set_camera(f, cam)
@@ -125,6 +133,7 @@ class GraphedRenderer:
             _lib.check(lib.gsr_forward(C.byref(f.params), f.geom.data_ptr(), f.binning.data_ptr(), f.nbytes, f.capacity,
                                        f.img.data_ptr(), f.radii.data_ptr(), f.color.data_ptr(), None, stream),
                        "gsr_forward (graph capture)")
+            torch.gt(f.radii, 0, out=f.visible)
         f.done = torch.cuda.Event()
         f.pending = False
 
@@ -143,11 +152,39 @@ class GraphedRenderer:
         return f.last_counts[0] <= f.capacity
 
     # ---- public ----------------------------------------------------------------------------------------------------
-    def render(self, viewpoint_camera, verify: bool = False) -> dict:
+    def _key(self, cam) -> tuple:
+        return (int(cam.image_height), int(cam.image_width), math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5))
+
+    def _result(self, f: _Format) -> dict:
+        return {"render": f.color, "viewspace_points": None, "visibility_filter": f.visible, "radii": f.radii,
+                "selected_pts_mask": None}
+
+    def _replay(self, f: _Format) -> None:
+        f.graph.replay()
+        f.done.record()
+        f.pending = True
+        f.frames += 1
+
+    def complete(self, viewpoint_camera) -> bool:
+        """Take the verdict of the last frame issued for this camera's format (host waits for that frame) and, if it
+        overflowed its capacity, render it again with a larger workspace on the current stream.  Returns True when the
+        frame had to be re-rendered.  After this call the format's buffers hold a complete frame."""
+        with torch.cuda.device(self.dev):
+            f = self.formats[self._key(viewpoint_camera)]
+            if self._verdict(f):
+                return False
+            self._capture(f, f.last_counts[0])
+            self._set_camera(f, viewpoint_camera)
+            self._replay(f)
+            if not self._verdict(f):      # cannot happen: the capacity now exceeds this very frame's count
+                raise _lib.GsrError("graphed frame overflowed twice")
+            return True
+
+    def render(self, viewpoint_camera, verify: bool = True) -> dict:
         """One frame.  The tensors of the result are STATIC buffers, overwritten by the next call for the same camera
-        format.  ``verify=True`` waits for the frame and re-renders it if its instance count exceeded the capacity."""
-        key = (int(viewpoint_camera.image_height), int(viewpoint_camera.image_width),
-               math.tan(viewpoint_camera.FoVx * 0.5), math.tan(viewpoint_camera.FoVy * 0.5))
+        format.  ``verify=True`` (default) waits for the frame and re-renders it if its instance count exceeded the
+        capacity; with ``verify=False`` the caller must call ``complete(camera)`` before using the frame."""
+        key = self._key(viewpoint_camera)
         with torch.cuda.device(self.dev):
             f = self.formats.get(key)
             if f is None:
@@ -155,23 +192,14 @@ class GraphedRenderer:
             elif not self._verdict(f):
                 need = f.last_counts[0]
                 self._capture(f, need)
-                raise _lib.GsrError(f"the previous graphed frame overflowed its binning capacity ({need} instances): its "
-                                    "image was incomplete; the graph has been rebuilt with a larger workspace "
-                                    "(render(..., verify=True) re-renders such a frame instead)")
+                raise _lib.GsrError(f"the previous graphed frame overflowed its binning capacity ({need} instances) and "
+                                    "nobody took its verdict (render(verify=False) without complete()): its image was "
+                                    "incomplete; the graph has been rebuilt with a larger workspace")
             self._set_camera(f, viewpoint_camera)
-            f.graph.replay()
-            f.done.record()
-            f.pending = True
-            f.frames += 1
-            if verify and not self._verdict(f):
-                self._capture(f, f.last_counts[0])
-                f.graph.replay()
-                f.done.record()
-                f.pending = True
-                if not self._verdict(f):      # cannot happen: the capacity now exceeds this very frame's count
-                    raise _lib.GsrError("graphed frame overflowed twice")
-        return {"render": f.color, "viewspace_points": None, "visibility_filter": f.radii > 0, "radii": f.radii,
-                "selected_pts_mask": None}
+            self._replay(f)
+        if verify:
+            self.complete(viewpoint_camera)
+        return self._result(f)
 
     def check(self) -> None:
         """Block until every issued frame has been checked; raises GsrError if the last frame of a format overflowed."""
@@ -200,7 +228,8 @@ class MultiStreamRenderer:
             save(out["render"])                        # (work issued on the current stream sees the finished frame)
         mr.check()
 
-    ``render_views`` keeps ``streams`` frames in flight and hands each one over once the CURRENT stream has been made to
+    ``render_views`` keeps ``streams`` frames in flight and hands each one over once its instance count has been
+    checked against the lane's capacity (re-rendered first if it did not fit) and the CURRENT stream has been made to
     wait for it; whatever the caller enqueues on the current stream afterwards (a copy to the host, an encoder) runs
     after the frame and before the lane's buffers are reused.
     """
@@ -212,7 +241,9 @@ class MultiStreamRenderer:
         if not pc.get_xyz.is_cuda:
             raise _lib.GsrError("MultiStreamRenderer needs the model on a ROCm GPU (no CPU path)")
         self.streams = [torch.cuda.Stream(self.dev) for _ in range(streams)]
-        self.lanes = [GraphedRenderer(pc, pipe, bg_color, scaling_modifier) for _ in range(streams)]
+        self.lanes = [GraphedRenderer(pc, pipe, bg_color, scaling_modifier)]
+        self.lanes += [GraphedRenderer(pc, pipe, bg_color, scaling_modifier, share_inputs_with=self.lanes[0])
+                       for _ in range(streams - 1)]
         self.done = [torch.cuda.Event() for _ in range(streams)]
         self.released = [None] * streams      # event on the consumer's stream after which a lane's buffers may be reused
         self.issued = 0
@@ -227,10 +258,10 @@ class MultiStreamRenderer:
         if self.released[k] is not None:
             s.wait_event(self.released[k])     # the consumer of this lane's previous frame has read it
         with torch.cuda.stream(s):
-            out = self.lanes[k].render(cam)
+            out = self.lanes[k].render(cam, verify=False)
             self.done[k].record(s)
         self.issued += 1
-        return k, out
+        return k, out, cam
 
     def render_views(self, cameras):
         """Generator of (index, result) in camera order with ``len(self.streams)`` frames in flight."""
@@ -245,7 +276,12 @@ class MultiStreamRenderer:
                 while nxt < len(cameras) and len(inflight) < n:
                     inflight.append(self._issue(cameras[nxt], inputs_ready))
                     nxt += 1
-                k, out = inflight.pop(0)
+                k, out, cam = inflight.pop(0)
+                # the frame's verdict BEFORE it is handed over (a host wait on this frame only; the later frames keep
+                # the GPU busy): a frame that overflowed its capacity is rendered again on its lane first
+                with torch.cuda.stream(self.streams[k]):
+                    if self.lanes[k].complete(cam):
+                        self.done[k].record(self.streams[k])
                 cur = torch.cuda.current_stream(self.dev)
                 cur.wait_event(self.done[k])
                 yield i, out

@@ -6,13 +6,20 @@ of ``include/gsr.h``; PyTorch only owns the memory and the stream.
 
 No CPU path exists: tensors must live on a ROCm device and the HIP library must be built.
 
-Host synchronisation.  Upstream reads ``num_rendered`` back in every forward to size its sort buffers.  Here only the
-first frame of a (device, P, W, H) combination does that (``gsr_forward_preprocess`` + ``gsr_forward_render``); later
-frames run ``gsr_forward`` with a caller-side capacity (1.5 x the largest instance count seen) and never stop the
-host.  The real count lands in pinned memory; it is compared with the capacity at the latest when the frame's
-backward starts, or when the next frame is issued -- a frame that overflowed raises ``GsrError`` there (its image
-and gradients are incomplete), and the capacity grows for the frames after it.  ``GSR_SYNC_FREE=0`` (read at import)
-or ``set_sync_free(False)`` keeps every frame on the two-call path.
+Host synchronisation.  Upstream reads ``num_rendered`` back in every forward to size its sort buffers: the GPU drains
+while the host round-trips, sizes the binning workspace and issues the second half of the frame.  Here only the first
+frame of a (device, P, W, H) combination does that (``gsr_forward_preprocess`` + ``gsr_forward_render``).  Later frames
+are ENQUEUED WHOLE by ``gsr_forward`` with a caller-side capacity (1.5 x the largest instance count seen); the host
+then waits for the event behind the scan kernel only (a third of the way into the frame: the GPU keeps the rest of the
+frame queued and never idles), compares the real count with the capacity and, if the frame did not fit, re-issues it on
+the two-call path with a workspace of the right size BEFORE the operator returns.  The operator therefore never raises
+and never hands out an incomplete image, whatever the camera sequence (``train.py:81-107`` draws a random camera per
+iteration, ``render.py:32-35`` saves every image at once) -- it is bit-identical to the per-frame read-back.
+
+``GSR_SYNC_FREE`` (read at import) / ``set_sync_free``:  ``1`` / ``True`` (default) the verified mode above;
+``0`` / ``False`` every frame on the two-call path;  ``deferred`` the count is compared with the capacity at the
+latest when the frame's backward starts, when the next frame is issued or in ``synchronize_counts()`` -- an overflowed
+frame raises ``GsrError`` THERE (its image and gradients are incomplete).  Only for callers that can redo a frame.
 """
 from __future__ import annotations
 
@@ -89,7 +96,27 @@ def _binning_from_name(name: str) -> int:
 
 _binning_mode_value = _binning_from_name(os.environ.get("GSR_BINNING", "culled"))
 _debug_flags_value = 0
-_sync_free_value = os.environ.get("GSR_SYNC_FREE", "1") != "0"
+SYNC_OFF, SYNC_VERIFIED, SYNC_DEFERRED = 0, 1, 2
+
+
+def _sync_mode_from(value) -> int:
+    if isinstance(value, str):
+        v = value.strip().lower()
+        if v in ("0", "off", "false", "no"):
+            return SYNC_OFF
+        if v in ("1", "on", "true", "yes", "verified", ""):
+            return SYNC_VERIFIED
+        if v in ("2", "deferred"):
+            return SYNC_DEFERRED
+        raise ValueError(f"sync-free mode must be 0 / 1 / deferred, got {value!r}")
+    if value is True or value is False:
+        return SYNC_VERIFIED if value else SYNC_OFF
+    if value in (SYNC_OFF, SYNC_VERIFIED, SYNC_DEFERRED):
+        return int(value)
+    raise ValueError(f"sync-free mode must be a bool, 0 / 1 / 2 or a name, got {value!r}")
+
+
+_sync_free_value = _sync_mode_from(os.environ.get("GSR_SYNC_FREE", "1"))
 
 
 def set_binning_mode(name: str) -> str:
@@ -109,12 +136,18 @@ def set_debug_flags(flags: int) -> int:
     return prev
 
 
-def set_sync_free(on: bool) -> bool:
-    """Whether frames after the first may run without the count read-back (module docstring); returns the previous
-    setting."""
+def set_sync_free(mode) -> int:
+    """How frames after the first of a shape are issued (module docstring): False / 0 = two calls with the count
+    read-back between them; True / 1 = enqueued whole, verified before the operator returns (default);
+    "deferred" / 2 = enqueued whole, verified later (an overflowed frame raises GsrError).  Returns the previous
+    setting (SYNC_OFF / SYNC_VERIFIED / SYNC_DEFERRED; pass it back to restore)."""
     global _sync_free_value
-    prev, _sync_free_value = _sync_free_value, bool(on)
+    prev, _sync_free_value = _sync_free_value, _sync_mode_from(mode)
     return prev
+
+
+def sync_free_mode() -> int:
+    return _sync_free_value
 
 
 def _stream(dev: torch.device) -> int:
@@ -161,16 +194,17 @@ def _round_ws(nbytes: int) -> int:
     return max(step, (int(nbytes) + step - 1) // step * step)
 
 
-# ---- deferred count check of the sync-free forward -----------------------------------------------------------------
+# ---- instance capacity of the frames issued without a count read-back ------------------------------------------------
 class _CapacityState:
     """Per (device, P, W, H, binning mode): the instance capacity later frames are issued with, and the workspaces
     forward-only frames share (nothing reads them after the frame: a fresh allocation per frame is pure host time)."""
-    __slots__ = ("capacity", "last_counts", "fo_ws")
+    __slots__ = ("capacity", "last_counts", "fo_ws", "reissued")
 
     def __init__(self):
         self.capacity = 0
         self.last_counts = (0, 0)
         self.fo_ws = {}         # stream handle -> (capacity, geom, img, binning) of the forward-only frames on that stream
+        self.reissued = 0       # frames that did not fit their capacity and were issued again (verified mode)
 
     def observe(self, R: int, V: int) -> None:
         self.last_counts = (R, V)
@@ -180,11 +214,11 @@ class _CapacityState:
 
 
 class _Pending:
-    """One sync-free frame whose instance count has not been compared with its capacity yet."""
-    __slots__ = ("event", "slot", "capacity", "state", "done", "counts", "error")
+    """One DEFERRED frame whose instance count has not been compared with its capacity yet."""
+    __slots__ = ("event", "slot", "capacity", "state", "done", "counts", "error", "dev_index")
 
-    def __init__(self, event, slot, capacity, state):
-        self.event, self.slot, self.capacity, self.state = event, slot, capacity, state
+    def __init__(self, event, slot, capacity, state, dev_index):
+        self.event, self.slot, self.capacity, self.state, self.dev_index = event, slot, capacity, state, dev_index
         self.done, self.counts, self.error = False, None, None
 
 
@@ -192,8 +226,10 @@ _MAX_STATES = 16
 _states: "collections.OrderedDict[tuple, _CapacityState]" = collections.OrderedDict()
 _pending: "collections.deque[_Pending]" = collections.deque()
 _free_slots: list = []
-_free_events: list = []
+_parked_slots: list = []    # (slot, device index) of frames whose enqueue failed half-way: a kernel may still write them
+_free_events: dict = {}     # device index -> HIP events created while that device was current
 _defer_lock = threading.RLock()
+_fo_owner = [None]          # the one state that keeps forward-only workspaces alive (~1 GB at 6 M Gaussians)
 
 
 def _state_for(key) -> _CapacityState:
@@ -208,13 +244,26 @@ def _state_for(key) -> _CapacityState:
         return st
 
 
-_RING = 64                  # frames that may be in flight unchecked; the host waits for the oldest beyond that
+def _keep_forward_only_ws(st: _CapacityState, stream: int, entry: tuple) -> None:
+    """Forward-only frames of one stream reuse one set of workspaces; only the most recently used state holds any (a
+    second resolution or a densified model takes the memory over instead of adding to it)."""
+    with _defer_lock:
+        owner = _fo_owner[0]
+        if owner is not None and owner is not st:
+            owner.fo_ws.clear()
+        _fo_owner[0] = st
+        if len(st.fo_ws) > 4:
+            st.fo_ws.clear()
+        st.fo_ws[stream] = entry
+
+
+_RING = 64                  # deferred frames that may be in flight unchecked; the host waits for the oldest beyond that
 _ring_store: list = []      # the one pinned allocation behind the slots (pin_memory() costs ~1 ms: never per frame)
 
 
 def _pinned_slot() -> torch.Tensor:
-    """A 64-byte slice of one pinned block for the counts of a frame.  When all slots are out, the oldest pending frame
-    is checked (blocking) to get its slot back."""
+    """A 64-byte slice of one pinned block for the counts of a deferred frame.  When all slots are out, the oldest
+    pending frame is checked (blocking) to get its slot back."""
     while True:
         with _defer_lock:
             if not _ring_store:
@@ -224,23 +273,41 @@ def _pinned_slot() -> torch.Tensor:
             if _free_slots:
                 return _free_slots.pop()
             oldest = _pending[0] if _pending else None
-        if oldest is None:
+            parked = list(_parked_slots)
+        if oldest is not None:
+            _verify(oldest, block=True)
+            continue
+        if not parked:
             raise _lib.GsrError("pinned count slots exhausted with nothing pending")
-        _verify(oldest, block=True)
+        for slot, dev_index in parked:      # frames whose enqueue failed: safe again once their device has drained
+            torch.cuda.synchronize(dev_index)
+        with _defer_lock:
+            for item in parked:
+                if item in _parked_slots:
+                    _parked_slots.remove(item)
+                    _free_slots.append(item[0])
 
 
-def _new_event() -> int:
+def _new_event(dev_index: int) -> int:
+    """A HIP event of device ``dev_index`` (the current device): events are pooled per device -- recording an event
+    on a stream of another device is an invalid-handle error."""
     with _defer_lock:
-        if _free_events:
-            return _free_events.pop()
+        pool = _free_events.get(dev_index)
+        if pool:
+            return pool.pop()
     ev = C.c_void_p()
     _lib.check(_lib.load().gsr_event_create(C.byref(ev)), "gsr_event_create")
     return ev.value
 
 
+def _release_event(event: int, dev_index: int) -> None:
+    with _defer_lock:
+        _free_events.setdefault(dev_index, []).append(event)
+
+
 def _verify(pend: _Pending, block: bool) -> bool:
-    """Compare the frame's real instance count with the capacity it ran with (waits for the scan kernel of that frame
-    when ``block``).  Raises GsrError for an overflowed frame -- every time it is asked about."""
+    """Compare a deferred frame's real instance count with the capacity it ran with (waits for the scan kernel of that
+    frame when ``block``).  Raises GsrError for an overflowed frame -- every time it is asked about."""
     with _defer_lock:
         if not pend.done:
             lib = _lib.load()
@@ -255,24 +322,24 @@ def _verify(pend: _Pending, block: bool) -> bool:
             pend.done, pend.counts = True, (R, V)
             pend.state.observe(R, V)
             _free_slots.append(pend.slot)
-            _free_events.append(pend.event)
+            _release_event(pend.event, pend.dev_index)
             pend.slot = pend.event = None
             try:
                 _pending.remove(pend)
             except ValueError:
                 pass
             if R > pend.capacity:
-                pend.error = (f"frame issued without a count read-back overflowed its binning capacity: {R} instances > "
-                              f"capacity {pend.capacity}; its image and gradients are incomplete and must be discarded "
-                              "(later frames get a larger capacity; set_sync_free(False) / GSR_SYNC_FREE=0 restores the "
-                              "per-frame read-back)")
+                pend.error = (f"frame issued in the DEFERRED sync-free mode overflowed its binning capacity: {R} instances "
+                              f"> capacity {pend.capacity}; its image and gradients are incomplete and must be discarded "
+                              "(later frames get a larger capacity; the default mode, set_sync_free(True), re-issues "
+                              "such a frame by itself)")
         if pend.error:
             raise _lib.GsrError(pend.error)
         return True
 
 
 def _drain_pending(block: bool = False) -> None:
-    """Check every earlier sync-free frame whose count has arrived (all of them when ``block``)."""
+    """Check every earlier deferred frame whose count has arrived (all of them when ``block``)."""
     while True:
         with _defer_lock:
             pend = _pending[0] if _pending else None
@@ -281,8 +348,8 @@ def _drain_pending(block: bool = False) -> None:
 
 
 def synchronize_counts() -> None:
-    """Block until every frame issued so far has had its instance count checked; raises GsrError if one overflowed.
-    Call it before trusting the image of a forward-only frame (e.g. before writing it to disk)."""
+    """Deferred mode only (a no-op otherwise: verified frames are checked before the operator returns).  Blocks until
+    every frame issued so far has had its instance count checked; raises GsrError if one overflowed."""
     _drain_pending(block=True)
 
 
@@ -294,17 +361,39 @@ def last_counts(dev, P: int, W: int, H: int) -> tuple:
         return st.last_counts if st is not None else (0, 0)
 
 
-_two_call_pinned = threading.local()
+def reissued_frames(dev, P: int, W: int, H: int) -> int:
+    """Frames of that shape that did not fit their capacity and were issued a second time (verified mode)."""
+    key = (torch.device(dev).index or 0, int(P), int(W), int(H), _binning_mode_value)
+    with _defer_lock:
+        st = _states.get(key)
+        return st.reissued if st is not None else 0
 
 
-def _counts_pinned_two_call() -> torch.Tensor:
-    """Per-thread pinned host buffer the scan kernel mirrors (num_rendered, num_visible, depth range) into: lets
-    gsr_forward_preprocess return as soon as the counts exist while the depth sort it enqueued keeps running."""
-    t = getattr(_two_call_pinned, "t", None)
+_thread_local = threading.local()
+
+
+def _counts_pinned_thread():
+    """Per-thread pinned host words the scan kernel mirrors (num_rendered, num_visible, depth range) into, and a ctypes
+    view of them.  A frame of the two-call or the verified path has read them before the operator returns, so one buffer
+    per thread serves every frame (forward and backward arrive on different threads)."""
+    t = getattr(_thread_local, "pinned", None)
     if t is None:
         t = torch.zeros(16, dtype=torch.int32).pin_memory()
-        _two_call_pinned.t = t
-    return t
+        _thread_local.pinned = t
+        _thread_local.words = (C.c_uint32 * 16).from_address(t.data_ptr())
+    return t, _thread_local.words
+
+
+def _thread_event(dev_index: int) -> int:
+    """The counts event of the verified path: one per (thread, device), reused by every frame (it is waited for before
+    the next frame can record it again)."""
+    evs = getattr(_thread_local, "events", None)
+    if evs is None:
+        evs = _thread_local.events = {}
+    ev = evs.get(dev_index)
+    if ev is None:
+        ev = evs[dev_index] = _new_event(dev_index)
+    return ev
 
 
 class _Frame(NamedTuple):
@@ -314,19 +403,23 @@ class _Frame(NamedTuple):
     img: torch.Tensor
     radii: torch.Tensor
     layout_R: int          # (num_rendered, num_visible) the workspaces are laid out for: the real counts after the
-    layout_V: int          #  two-call forward, (capacity, P) after the sync-free one
-    pending: Optional[_Pending]
+    layout_V: int          #  two-call forward, (capacity, P) after gsr_forward
+    pending: Optional[_Pending]     # deferred mode: the check that has not happened yet
+    counts: Optional[tuple]         # the real (num_rendered, num_visible) when known
 
 
 def _run_forward(lib, dev, params, P: int, W: int, H: int):
     """Native forward on torch's current stream.  Returns (color, _Frame)."""
     stream = _stream(dev)
+    dev_index = dev.index or 0
     radii = torch.empty(P, dtype=torch.int32, device=dev)      # written for every Gaussian by the kernel
     color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
     mode = params.binning_mode
-    st = _state_for((dev.index or 0, P, W, H, mode))
-    _drain_pending()
-    sync_free = _sync_free_value and st.capacity > 0 and mode != _lib.BINNING_KEYS64 and P > 0
+    st = _state_for((dev_index, P, W, H, mode))
+    if _pending:
+        _drain_pending()
+    sync_mode = _sync_free_value
+    sync_free = sync_mode != SYNC_OFF and st.capacity > 0 and mode != _lib.BINNING_KEYS64 and P > 0
     cached = st.fo_ws.get(stream) if (sync_free and params.forward_only) else None
     if cached is not None and cached[0] == st.capacity:
         # forward-only frames of one stream run one after the other and nothing outlives them: same workspaces every frame
@@ -337,29 +430,46 @@ def _run_forward(lib, dev, params, P: int, W: int, H: int):
         binning = None
     if sync_free:
         cap = st.capacity
-        slot, event = _pinned_slot(), _new_event()
-        params.counts_pinned = slot.data_ptr()
         nbytes = lib.gsr_binning_bytes(cap, P, W, H, mode)
         if binning is None:
             binning = torch.empty(_round_ws(nbytes), dtype=torch.uint8, device=dev)
             if params.forward_only:
-                if len(st.fo_ws) > 4:
-                    st.fo_ws.clear()
-                st.fo_ws[stream] = (cap, geom, img, binning)
-        pend = _Pending(event, slot, cap, st)
-        slot[0] = 0                 # a frame whose enqueue fails half-way must not be read as an overflow later
-        try:
-            _lib.check(lib.gsr_forward(C.byref(params), geom.data_ptr(), binning.data_ptr(), nbytes, cap, img.data_ptr(),
-                                       radii.data_ptr(), color.data_ptr(), event, stream), "gsr_forward")
-        except _lib.GsrError:
-            with _defer_lock:       # nothing of this frame is pending: give the slot and the event back
-                _free_slots.append(slot)
-                _free_events.append(event)
-            raise
-        with _defer_lock:
-            _pending.append(pend)
-        return color, _Frame(geom, binning, img, radii, cap, P, pend)
-    pinned = _counts_pinned_two_call()
+                _keep_forward_only_ws(st, stream, (cap, geom, img, binning))
+        if sync_mode == SYNC_DEFERRED:
+            slot, event = _pinned_slot(), _new_event(dev_index)
+            params.counts_pinned = slot.data_ptr()
+            pend = _Pending(event, slot, cap, st, dev_index)
+            slot[0] = 0             # a frame whose enqueue fails half-way must not be read as an overflow later
+            try:
+                _lib.check(lib.gsr_forward(C.byref(params), geom.data_ptr(), binning.data_ptr(), nbytes, cap, img.data_ptr(),
+                                           radii.data_ptr(), color.data_ptr(), event, stream), "gsr_forward")
+            except _lib.GsrError:
+                with _defer_lock:   # the scan kernel may already be queued and will write the slot: park it until the
+                    _parked_slots.append((slot, dev_index))     # device has drained; the event was never recorded
+                _release_event(event, dev_index)
+                raise
+            with _defer_lock:
+                _pending.append(pend)
+            return color, _Frame(geom, binning, img, radii, cap, P, pend, None)
+        # verified mode: the whole frame is queued, the host waits for its scan kernel only
+        pinned, words = _counts_pinned_thread()
+        params.counts_pinned = pinned.data_ptr()
+        event = _thread_event(dev_index)
+        _lib.check(lib.gsr_forward(C.byref(params), geom.data_ptr(), binning.data_ptr(), nbytes, cap, img.data_ptr(),
+                                   radii.data_ptr(), color.data_ptr(), event, stream), "gsr_forward")
+        _lib.check(lib.gsr_event_wait(event), "gsr_event_wait")
+        R, V = int(words[0]), int(words[1])
+        st.observe(R, V)
+        if R <= cap:
+            return color, _Frame(geom, binning, img, radii, cap, P, None, (R, V))
+        # The frame did not fit: its kernels dropped the instances past the capacity (no out-of-bounds access) and are
+        # still running.  Issue it again behind them, on the two-call path, into the same outputs -- nothing of the
+        # truncated frame has left the operator.
+        st.reissued += 1
+        if params.forward_only:
+            with _defer_lock:
+                st.fo_ws.pop(stream, None)
+    pinned, _words = _counts_pinned_thread()
     params.counts_pinned = pinned.data_ptr()
     num_rendered, num_visible = C.c_uint32(0), C.c_uint32(0)
     _lib.check(lib.gsr_forward_preprocess(C.byref(params), geom.data_ptr(), _ptr(radii), stream,
@@ -370,12 +480,12 @@ def _run_forward(lib, dev, params, P: int, W: int, H: int):
     binning = torch.empty(_round_ws(nbytes), dtype=torch.uint8, device=dev)
     _lib.check(lib.gsr_forward_render(C.byref(params), geom.data_ptr(), binning.data_ptr(), nbytes, img.data_ptr(),
                                       R, V, color.data_ptr(), stream), "gsr_forward_render")
-    return color, _Frame(geom, binning, img, radii, R, V, None)
+    return color, _Frame(geom, binning, img, radii, R, V, None, (R, V))
 
 
 def _run_backward(lib, dev, params, frame: _Frame, grad_out_color: torch.Tensor, grads: "_lib.GsrGrads") -> None:
     if frame.pending is not None:
-        _verify(frame.pending, block=True)      # the scan kernel of this frame's forward finished long ago
+        _verify(frame.pending, block=True)      # deferred mode: the scan kernel of this frame's forward finished long ago
     P = int(params.P)
     nbytes = lib.gsr_backward_bytes(P, frame.layout_R)
     bwd_ws = torch.empty(_round_ws(nbytes), dtype=torch.uint8, device=dev)
@@ -386,7 +496,7 @@ def _run_backward(lib, dev, params, frame: _Frame, grad_out_color: torch.Tensor,
 
 def frame_counts(color: torch.Tensor) -> tuple:
     """(num_rendered, num_visible) of the frame that produced ``color`` (an output of the operator that still carries
-    its autograd node).  Waits for the count of a frame that ran without the read-back; raises if it overflowed."""
+    its autograd node).  In deferred mode: waits for the frame's count; raises if it overflowed."""
     ctx = color.grad_fn
     if ctx is None or not hasattr(ctx, "frame_pending"):
         raise ValueError("not an output of the rasterizer with an autograd node (rendered under no_grad?)")
@@ -394,7 +504,7 @@ def frame_counts(color: torch.Tensor) -> tuple:
     if pend is not None:
         _verify(pend, block=True)
         return pend.counts
-    return ctx.layout
+    return ctx.counts
 
 
 def _stats_ptrs(stats, P: int, dev):
@@ -451,6 +561,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.profile = _lib.active_profile()     # backward runs on an autograd thread: carry the (live) object explicitly
         ctx.layout = (frame.layout_R, frame.layout_V)
         ctx.frame_pending = frame.pending
+        ctx.counts = frame.counts
         ctx.binning_mode = params.binning_mode
         ctx.stats = stats
         ctx.keep = keep
@@ -483,7 +594,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_cov = new(P, 6) if cov3Ds_precomp.numel() else None
             grads = _lib.GsrGrads(_ptr(g_means3D), _ptr(g_means2D), _ptr(g_sh), _ptr(g_col), _ptr(g_opac),
                                   _ptr(g_scales), _ptr(g_rot), _ptr(g_cov), None, *_stats_ptrs(ctx.stats, P, dev))
-            frame = _Frame(geom, binning, img, radii, ctx.layout[0], ctx.layout[1], ctx.frame_pending)
+            frame = _Frame(geom, binning, img, radii, ctx.layout[0], ctx.layout[1], ctx.frame_pending, ctx.counts)
             try:
                 _run_backward(lib, dev, params, frame, grad_out_color, grads)
             except _lib.GsrError:
@@ -544,6 +655,7 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
         ctx.profile = _lib.active_profile()
         ctx.layout = (frame.layout_R, frame.layout_V)
         ctx.frame_pending = frame.pending
+        ctx.counts = frame.counts
         ctx.binning_mode = params.binning_mode
         ctx.act_flags = flags
         ctx.stats = stats
@@ -574,7 +686,7 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
             g_opac, g_scales, g_rot = new(*raw_opacity.shape), new(P, 3), new(P, 4)
             grads = _lib.GsrGrads(_ptr(g_means3D), _ptr(g_means2D), _ptr(g_dc), None, _ptr(g_opac), _ptr(g_scales),
                                   _ptr(g_rot), None, _ptr(g_rest) if has_rest else None, *_stats_ptrs(ctx.stats, P, dev))
-            frame = _Frame(geom, binning, img, radii, ctx.layout[0], ctx.layout[1], ctx.frame_pending)
+            frame = _Frame(geom, binning, img, radii, ctx.layout[0], ctx.layout[1], ctx.frame_pending, ctx.counts)
             try:
                 _run_backward(lib, dev, params, frame, grad_out_color, grads)
             except _lib.GsrError:

@@ -83,6 +83,7 @@ def grads_oracle(model, settings, target, *, dtype=torch.float64, use_cov=False,
     from oracle import rasterize_ref
     leaves, xyz, m2, op, kw = oracle_operator_inputs(model, dtype, use_cov, use_colors)
     col, radii, aux = rasterize_ref(xyz, m2, op, settings, want_aux=True, want_margin=True, tiles=tiles, **kw)
+    aux["radii"] = radii.detach()
     if weight is None:
         weight = loss_weight(col, target, aux["margin"], tile_mask)
     masked_l1(col, target, weight).backward()

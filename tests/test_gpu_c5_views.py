@@ -1,0 +1,134 @@
+"""BASELINE config 5 as far as one GPU can take it: the EIGHT orbit views of the 6 M-Gaussian cloud (view v =
+the camera rotated by 45 deg * v about the cloud centre), each at full size (1920x1080, SH degree 3).
+
+* the train step the reference runs per iteration (``train.py:81-107,130-131``: a different camera every time, render ->
+  loss -> backward -> densification statistics) over all eight views, in the default host-synchronisation mode (frames
+  enqueued whole with a capacity, verified before the operator returns) with the capacity the earlier views taught it AND
+  with a capacity forced far below every view's count: never raises, and image, radii, every gradient and the statistics
+  are bit-identical to the per-frame read-back (``set_sync_free(False)``);
+* the size-independent properties of the lists, ranges and pixels on the rotated views 1..7 (view 0 has them in
+  ``test_gpu_parity.py``): sortedness, ties in index order, ranges partition the list, one instance per overlapped tile,
+  sum(w) + T_final = 1, culled == un-culled pixels, run-to-run determinism.
+
+The masked float64 comparison of a rotated view is ``test_gpu_parity.py::test_config_C4_masked_train_step_matches_fp64_oracle[3]``.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+N_VIEWS = 8
+
+
+def bits_checksum(t: torch.Tensor) -> tuple:
+    """Two integer sums over the BIT PATTERNS of a tensor (plain and position-weighted): equal checksums of two runs of
+    a deterministic kernel mean equal bits, without keeping 1.4 GB of gradients per view around."""
+    v = t.detach().contiguous().view(torch.int32).reshape(-1).to(torch.int64)
+    w = (torch.arange(v.numel(), device=v.device, dtype=torch.int64) % 65521) + 1
+    return int(v.sum()), int((v * w).sum())
+
+
+@pytest.fixture(scope="module")
+def c4_on_gpu(gpu_device):
+    from mvs_gaussian_splatting_amd.synthetic import CONFIGS, make_scene, orbit_camera
+    cfg = CONFIGS["C4"]
+    model, _, bg, target = make_scene(cfg)
+    model.to(gpu_device)
+    for p in model.parameters():
+        p.requires_grad_(True)
+    cams = [orbit_camera(v, N_VIEWS, cfg.width, cfg.height, cfg.fx, cfg.fy, device=gpu_device) for v in range(N_VIEWS)]
+    return cfg, model, cams, bg.to(gpu_device), target.to(gpu_device)
+
+
+def test_eight_view_train_steps_never_raise_and_equal_the_per_frame_readback(gpu_device, c4_on_gpu):
+    from mvs_gaussian_splatting_amd import render, l1_loss, add_densification_stats, rasterizer as rz
+    from mvs_gaussian_splatting_amd.synthetic import PipelineParams
+    cfg, model, cams, bg, target = c4_on_gpu
+    P = model._xyz.shape[0]
+    pipe = PipelineParams()
+
+    def run(mode, squeeze_to=None):
+        prev = rz.set_sync_free(mode)
+        rz._states.clear()
+        for t in (model.xyz_gradient_accum, model.denom, model.max_radii2D):
+            t.zero_()
+        out = []
+        try:
+            for v in range(N_VIEWS):
+                if squeeze_to is not None:
+                    for st in rz._states.values():
+                        st.capacity = squeeze_to
+                for p in model.parameters():
+                    p.grad = None
+                pkg = render(cams[v], model, pipe, bg)
+                l1_loss(pkg["render"], target).backward()
+                add_densification_stats(model, pkg["viewspace_points"], pkg["radii"])
+                sums = [bits_checksum(pkg["render"]), bits_checksum(pkg["radii"]), bits_checksum(pkg["viewspace_points"].grad)]
+                sums += [bits_checksum(p.grad) for p in model.parameters()]
+                out.append((rz.frame_counts(pkg["render"]), sums))
+            stats = [bits_checksum(t) for t in (model.xyz_gradient_accum, model.denom, model.max_radii2D)]
+            reissued = rz.reissued_frames(gpu_device, P, cfg.width, cfg.height)
+        finally:
+            rz.set_sync_free(prev)
+        return out, stats, reissued
+
+    ref, ref_stats, _ = run(False)
+    counts = [c[0][0] for c in ref]
+    print(f"[C5 views] instances per view: {counts}; visible: {[c[0][1] for c in ref]}")
+    assert min(counts) > 1_000_000
+    nat, nat_stats, nat_reissued = run(True)                       # the capacity the earlier views taught it
+    sq, sq_stats, sq_reissued = run(True, squeeze_to=1 << 20)      # 2^20 instances: every frame after the first overflows
+    print(f"[C5 views] frames issued twice: natural capacity {nat_reissued}, forced capacity {sq_reissued}")
+    assert sq_reissued == N_VIEWS - 1
+    # a view whose count exceeds 1.5 x everything before it must have been re-issued in the natural run
+    must = sum(1 for i in range(1, N_VIEWS) if counts[i] > ((int(max(counts[:i]) * 1.5) + (1 << 20)) >> 20 << 20))
+    assert nat_reissued == must
+    for got, got_stats in ((nat, nat_stats), (sq, sq_stats)):
+        for v, ((cnt, sums), (cnt0, sums0)) in enumerate(zip(got, ref)):
+            assert cnt == cnt0, f"view {v}: counts {cnt} != {cnt0}"
+            assert sums == sums0, f"view {v}: image / radii / gradients differ from the per-frame read-back"
+        assert got_stats == ref_stats
+
+
+@pytest.mark.parametrize("view", list(range(1, N_VIEWS)))
+def test_rotated_view_full_size_properties(gpu_device, c4_on_gpu, view):
+    from gpu_util import forward_with_state, product_settings
+    from mvs_gaussian_splatting_amd import GaussianRasterizer, render
+    from mvs_gaussian_splatting_amd.synthetic import PipelineParams
+    cfg, model, cams, bg, _ = c4_on_gpu
+    cam = cams[view]
+    dev = gpu_device
+    st = product_settings(cam, bg, cfg.sh_degree, dev)
+    with torch.no_grad():
+        xyz, op, feats = model.get_xyz, model.get_opacity, model.get_features
+        scales, rots = model.get_scaling, model.get_rotation
+        o = forward_with_state(dev, st, xyz, op, shs=feats, scales=scales, rotations=rots, binning_mode=0)
+        keys, plist, ranges, tiles = o["keys"], o["point_list"], o["ranges"], o["tiles"]
+        assert o["R"] == int(tiles.sum()) == keys.size and o["V"] == int((o["radii"] > 0).sum()) > 0
+        assert np.all(keys[1:] >= keys[:-1])                                   # sorted by (tile, depth)
+        same = keys[1:] == keys[:-1]
+        assert np.all(plist[1:][same] > plist[:-1][same])                      # ties in Gaussian-index order
+        ne = ranges[:, 1] > ranges[:, 0]
+        assert int((ranges[ne, 1] - ranges[ne, 0]).sum()) == o["R"]            # ranges partition the list
+        starts = np.sort(ranges[ne, 0])
+        assert starts[0] == 0 and np.all(np.diff(starts) > 0)
+        tile_of = (keys >> np.uint64(32)).astype(np.int64)
+        assert np.array_equal(np.bincount(tile_of, minlength=ranges.shape[0]), ranges[:, 1] - ranges[:, 0])
+        assert np.array_equal(np.bincount(plist, minlength=tiles.size), tiles)  # one instance per overlapped tile
+        del keys, plist, tile_of
+        # the product path (culled binning, raw parameters) renders the same pixels as the un-culled getter-fed lists up
+        # to the activations' rounding, twice the same bits, and the getter-fed culled frame the SAME bits as the un-culled
+        a = render(cam, model, PipelineParams(), bg)["render"]
+        b = render(cam, model, PipelineParams(), bg)["render"]
+        assert torch.equal(a, b)
+        c, radii = GaussianRasterizer(st)(means3D=xyz, means2D=None, opacities=op, shs=feats, scales=scales, rotations=rots)
+        assert torch.equal(c.cpu(), o["color"]) and torch.equal(radii.cpu(), o["radii"])
+        assert float((a - c).abs().max()) <= 2.0 / 255.0
+        # sum(w) + T_final = 1 on every pixel: colour 1 on background 1
+        st1 = product_settings(cam, torch.ones(3), 0, dev)
+        ones = torch.ones(xyz.shape[0], 3, device=dev)
+        col, _ = GaussianRasterizer(st1)(means3D=xyz, means2D=None, opacities=op, colors_precomp=ones, scales=scales,
+                                         rotations=rots)
+        assert float((col - 1.0).abs().max()) < 1.2e-4                         # <= T_STOP of mass lost at saturation
+    print(f"[C5 view {view}] R = {o['R']}, V = {o['V']}")

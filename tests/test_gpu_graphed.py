@@ -69,7 +69,7 @@ def test_graphed_overflow_is_detected_and_repaired(gpu_device):
         got = gr.render(cams[1], verify=True)["render"]          # overflow seen at once, frame re-rendered
         assert torch.equal(got, want) and f.capacity >= int(1.5 * true_R)
         f.capacity = 0
-        gr.render(cams[2])                                       # deferred: reported by the next call ...
+        gr.render(cams[2], verify=False)                         # verdict left to the caller, who does not take it:
         with pytest.raises(_lib.GsrError, match="overflowed"):
             gr.render(cams[0])
         assert torch.equal(gr.render(cams[2], verify=True)["render"], render(cams[2], model, PipelineParams(), bg)["render"])
@@ -99,3 +99,13 @@ def test_multi_stream_frames_equal_eager_frames(gpu_device, streams):
         for cam, got in zip(cams, kept):
             assert torch.equal(got, render(cam, model, PipelineParams(), bg)["render"])
     assert sum(next(iter(l.formats.values())).frames for l in mr.lanes) == len(cams)
+    assert all(l.inputs is mr.lanes[0].inputs for l in mr.lanes)            # one snapshot of the parameters, shared
+    # a lane whose capacity is too small for its frame re-renders it BEFORE handing it over
+    for lane in mr.lanes:
+        for f in lane.formats.values():
+            f.capacity = 0
+    with torch.no_grad():
+        for i, out in mr.render_views(cams[:2 * streams]):
+            assert torch.equal(out["render"], render(cams[i], model, PipelineParams(), bg)["render"])
+        mr.check()
+    assert all(f.capacity > 0 for lane in mr.lanes for f in lane.formats.values())

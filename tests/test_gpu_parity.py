@@ -415,18 +415,18 @@ def test_config_C2_full_forward_matches_oracle(gpu_device):
     assert torch.equal(out["n_contrib"][robust], aux["n_contrib"][robust])
 
 
-def test_config_C3_masked_train_step_matches_fp64_oracle(gpu_device):
-    """C3: 1 M Gaussians, SH degree 3, 1920x1080, forward + backward.  The L1 loss is restricted to 40 tiles
-    spread over the image (mask), so that the float64 autograd oracle only has to composite those tiles; the HIP
-    path runs the whole frame and must produce the same pixels there and the same parameter gradients."""
-    from mvs_gaussian_splatting_amd import render
+def _masked_train_step_vs_fp64_oracle(dev, cfg_name, view, tile_step, label, check_stats=False):
+    """One train step of a BASELINE config at its real size.  The L1 loss is restricted to ~40 tiles spread over the
+    image (mask), so that the float64 autograd oracle only has to composite those tiles; the HIP path runs the whole frame
+    and must produce the same pixels there and the same parameter gradients (tests/grad_util.py bar)."""
+    from mvs_gaussian_splatting_amd import render, add_densification_stats
     from mvs_gaussian_splatting_amd.synthetic import CONFIGS, make_scene, PipelineParams
     import os
     torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
-    cfg = CONFIGS["C3"]
-    model, cam, bg, target = make_scene(cfg)
+    cfg = CONFIGS[cfg_name]
+    model, cam, bg, target = make_scene(cfg, view=view)
     gx, gy = (cfg.width + 15) // 16, (cfg.height + 15) // 16
-    tiles = [ty * gx + tx for ty in range(3, gy, 14) for tx in range(5, gx, 15)]
+    tiles = [ty * gx + tx for ty in range(3, gy, tile_step[1]) for tx in range(5, gx, tile_step[0])]
     mask = torch.zeros(1, cfg.height, cfg.width)
     for t in tiles:
         ty, tx = divmod(t, gx)
@@ -435,9 +435,8 @@ def test_config_C3_masked_train_step_matches_fp64_oracle(gpu_device):
     from grad_util import grads_oracle, compare_grads, masked_l1
     st = make_settings(cam, bg, cfg.sh_degree)
     ref, weight, aux, col = grads_oracle(model, st, target, tiles=tiles, tile_mask=mask)
-    ref32, _, _, _ = grads_oracle(model, st, target, dtype=torch.float32, tiles=tiles, weight=weight)
+    ref32, _, _, col32 = grads_oracle(model, st, target, dtype=torch.float32, tiles=tiles, weight=weight)
     # ---- HIP path, whole frame -------------------------------------------------------------------------
-    dev = gpu_device
     model.to(dev); cam.to(dev)
     for p in model.parameters():
         p.requires_grad_(True)
@@ -446,14 +445,66 @@ def test_config_C3_masked_train_step_matches_fp64_oracle(gpu_device):
     masked_l1(img, target, weight).backward()
     m = mask[0].bool()
     robust = (aux["margin"] > 1e-4) & m
-    err = (img.detach().cpu() - col.float()).abs().max(dim=0).values
-    assert float(err[robust].max()) <= 1e-5
+    # pixels, relative to max(1, |ref|) (colours of a degree-3 cloud exceed 1) as in the C2 test.  Two bars:
+    #  (a) against the float32 oracle 1e-5 -- north_star's bar is float32 against float32 (the reference rasterizer
+    #      computes in float32);
+    #  (b) against float64 1e-5 wherever float32 can deliver it: a pixel with several hundred contributors accumulates
+    #      more float32 rounding than that, so the bar of a pixel is 2 x the float32 oracle's own error there, never more
+    #      than 1e-4 (the rule of grad_util.compare_grads, per pixel).
+    rel = lambda x, r: ((x.double() - r.double()).abs() / r.double().abs().clamp(min=1.0)).max(dim=0).values  # noqa: E731
+    got = img.detach().cpu()
+    err, err32, err_vs32 = rel(got, col), rel(col32, col), rel(got, col32)
+    worst = int(torch.where(robust, err, torch.zeros_like(err)).argmax())
+    wy, wx = divmod(worst, cfg.width)
+    print(f"[pixels] {label}: vs float64: worst robust pixel ({wx},{wy}) err {float(err[wy, wx]):.2e} (float32 oracle there "
+          f"{float(err32[wy, wx]):.2e}, its own worst {float(err32[robust].max()):.2e}), |ref| {float(col[:, wy, wx].abs().max()):.3f}, "
+          f"contributors {int(aux['n_contrib'][wy, wx])}, mean {float(err[robust].mean()):.2e}; vs the float32 oracle: worst "
+          f"{float(err_vs32[robust].max()):.2e}, mean {float(err_vs32[robust].mean()):.2e}")
+    assert float(err_vs32[robust].max()) <= 1e-5
+    bar = (2.0 * err32).clamp(min=1e-5)
+    assert float(bar[robust].max()) <= 1e-4, "float32 itself is too far from float64 on a pixel of this scene"
+    assert bool((err[robust] <= bar[robust]).all())
     n_fragile = int(((aux["margin"] <= 1e-4) & m).sum())
+    assert n_fragile <= 0.02 * int(m.sum())
     got = {"xyz": model._xyz.grad, "f_dc": model._features_dc.grad, "f_rest": model._features_rest.grad,
            "opacity": model._opacity.grad, "scaling": model._scaling.grad, "rotation": model._rotation.grad,
            "means2D": pkg["viewspace_points"].grad}
     compare_grads({k: v.detach().cpu() for k, v in got.items()}, ref, ref32,
-                  f"C3 masked train step ({len(tiles)} tiles, fragile pixels {n_fragile})")
+                  f"{label} ({len(tiles)} tiles, fragile pixels {n_fragile})")
+    if check_stats:
+        # densification statistics of the step (scene/gaussian_model.py:775-777, train.py:130) against the oracle's
+        # ||dL/dmeans2D[:, :2]|| -- same max-norm bar as the means2D gradient itself
+        radii = pkg["radii"]
+        vis = (radii > 0).cpu()
+        assert torch.equal(radii.cpu(), aux["radii"].to(torch.int32))
+        add_densification_stats(model, pkg["viewspace_points"], radii)
+        want = ref["means2D"][:, :2].norm(dim=1).double()
+        want32 = ref32["means2D"][:, :2].norm(dim=1).double()
+        acc = model.xyz_gradient_accum.detach().cpu().double().reshape(-1)
+        scale = float(want.abs().max())
+        e, e32 = float((acc - want)[vis].abs().max()) / scale, float((want32 - want)[vis].abs().max()) / scale
+        print(f"[densify stats] {label}: xyz_gradient_accum err {e:.2e} (float32 oracle {e32:.2e})")
+        assert e <= max(1e-5, 2.0 * e32) <= 2e-4
+        assert float(acc[~vis].abs().max()) == 0.0
+        assert torch.equal(model.denom.detach().cpu().reshape(-1), vis.float())
+        assert torch.equal(model.max_radii2D.detach().cpu(), torch.where(vis, radii.cpu().float(), torch.zeros(())))
+    return len(tiles), n_fragile
+
+
+def test_config_C3_masked_train_step_matches_fp64_oracle(gpu_device):
+    """C3: 1 M Gaussians, SH degree 3, 1920x1080, forward + backward."""
+    n, _ = _masked_train_step_vs_fp64_oracle(gpu_device, "C3", 0, (15, 14), "C3 masked train step")
+    assert n == 40
+
+
+@pytest.mark.parametrize("view", [0, 3])
+def test_config_C4_masked_train_step_matches_fp64_oracle(gpu_device, view):
+    """C4, the config the headline metric is quoted on: 6 M Gaussians, SH degree 3, 1920x1080, forward + backward +
+    densification statistics.  view 0 is the bench's camera; view 3 one of C5's rotated cameras (135 degrees about the
+    cloud centre: the camera stands inside the cloud, splats near the camera are hundreds of pixels wide)."""
+    n, _ = _masked_train_step_vs_fp64_oracle(gpu_device, "C4", view, (15, 14), f"C4 view {view} masked train step",
+                                             check_stats=True)
+    assert n == 40
 
 
 @pytest.mark.parametrize("N,kind", [(4, "uniform"), (129, "uniform"), (1000, "uniform"), (200_000, "uniform"),

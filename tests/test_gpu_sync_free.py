@@ -2,8 +2,10 @@
 overflow visible in pinned memory) against the two-call forward it replaces after the first frame
 (``gsr_forward_preprocess`` + ``gsr_forward_render``, i.e. upstream's per-forward ``num_rendered`` read-back,
 ``gaussian_renderer/__init__.py:257-265``): images, radii, per-pixel state and every gradient must be BIT-IDENTICAL;
-a capacity that is too small must be reported, never silently rendered; frames whose depths span more than 24 bits
-take the device-predicated fourth sort pass.  Also the fused densification statistics (``GsrGrads.stats_*``) and the
+a frame that does not fit its capacity is issued again before the operator returns (default, "verified" mode: the
+operator never raises and never hands out an incomplete image, whatever the camera sequence -- ``train.py:81-107``,
+``render.py:32-35``) or reported loudly (opt-in "deferred" mode); frames whose depths span more than 24 bits take the
+device-predicated fourth sort pass.  Also the fused densification statistics (``GsrGrads.stats_*``) and the
 roctx switch."""
 import ctypes as C
 import math
@@ -50,7 +52,7 @@ def fresh_state(monkeypatch):
     from mvs_gaussian_splatting_amd import rasterizer
     rasterizer.synchronize_counts()
     rasterizer._states.clear()
-    monkeypatch.setattr(rasterizer, "_sync_free_value", True)
+    monkeypatch.setattr(rasterizer, "_sync_free_value", rasterizer.SYNC_VERIFIED)
     yield rasterizer
     try:
         rasterizer.synchronize_counts()
@@ -59,23 +61,31 @@ def fresh_state(monkeypatch):
     rasterizer._states.clear()
 
 
+@pytest.mark.parametrize("mode", ["verified", "deferred"])
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("wide_depth", [False, True])
-def test_second_frame_runs_without_readback_and_is_bit_identical(gpu_device, fresh_state, fused, wide_depth):
+def test_second_frame_runs_without_readback_and_is_bit_identical(gpu_device, fresh_state, fused, wide_depth, mode):
     rz = fresh_state
+    rz.set_sync_free(mode)
     model, cam, bg, target = _scene(gpu_device, wide_depth=wide_depth)
     pkg0, g0 = _step(model, cam, bg, target, fused)                 # first frame: two-call path, learns the capacity
-    assert pkg0["render"].grad_fn.frame_pending is None
+    ctx0 = pkg0["render"].grad_fn
+    assert ctx0.frame_pending is None
     R0, V0 = rz.frame_counts(pkg0["render"])
-    assert R0 > V0 > 1000
-    pkg1, g1 = _step(model, cam, bg, target, fused)                 # second frame: gsr_forward
-    pend = pkg1["render"].grad_fn.frame_pending
-    assert pend is not None and pend.done and pend.capacity >= int(1.5 * R0)
+    assert R0 > V0 > 1000 and ctx0.layout == (R0, V0)
+    pkg1, g1 = _step(model, cam, bg, target, fused)                 # second frame: gsr_forward, laid out for a capacity
+    ctx1 = pkg1["render"].grad_fn
+    assert ctx1.layout[0] >= int(1.5 * R0) and ctx1.layout[1] == model._xyz.shape[0]
+    if mode == "deferred":
+        pend = ctx1.frame_pending
+        assert pend is not None and pend.done and pend.capacity == ctx1.layout[0]
+    else:
+        assert ctx1.frame_pending is None and ctx1.counts == (R0, V0)
     assert rz.frame_counts(pkg1["render"]) == (R0, V0)
     assert torch.equal(pkg0["render"], pkg1["render"]) and torch.equal(pkg0["radii"], pkg1["radii"])
     for a, b in zip(g0, g1):
         assert torch.equal(a, b)
-    # forward-only frames (no autograd node): checked by synchronize_counts
+    # forward-only frames (no autograd node)
     with torch.no_grad():
         from mvs_gaussian_splatting_amd import render
         from mvs_gaussian_splatting_amd.synthetic import PipelineParams
@@ -83,6 +93,7 @@ def test_second_frame_runs_without_readback_and_is_bit_identical(gpu_device, fre
     rz.synchronize_counts()
     assert torch.equal(img, pkg0["render"].detach())
     assert rz.last_counts(gpu_device, model._xyz.shape[0], cam.image_width, cam.image_height) == (R0, V0)
+    assert rz.reissued_frames(gpu_device, model._xyz.shape[0], cam.image_width, cam.image_height) == 0
 
 
 def test_raw_abi_lists_and_state_are_those_of_the_two_call_path(gpu_device):
@@ -110,8 +121,91 @@ def test_raw_abi_lists_and_state_are_those_of_the_two_call_path(gpu_device):
                     assert torch.equal(out[k], ref[k]), k
 
 
-def test_overflow_is_reported_not_rendered_silently(gpu_device, fresh_state):
+def _views(P, n=4, **kw):
+    return [small_scene(P=P, sh_degree=2, width=352, height=208, scale=0.03, view=v, **kw)[1] for v in range(n)]
+
+
+def test_overflow_is_recovered_before_the_operator_returns(gpu_device, fresh_state):
+    """Default mode: a frame that does not fit the capacity it was issued with is issued again, inside the forward --
+    the caller sees the complete image, the backward the complete state; nothing raises; everything is bit-identical to
+    the per-frame read-back."""
     rz = fresh_state
+    model, cam, bg, target = _scene(gpu_device)
+    P = model._xyz.shape[0]
+    prev = rz.set_sync_free(False)
+    pkg_ref, g_ref = _step(model, cam, bg, target)
+    rz.set_sync_free(prev)
+    rz._states.clear()
+    pkg0, _ = _step(model, cam, bg, target)
+    R0, _ = rz.frame_counts(pkg0["render"])
+    key_state = next(iter(rz._states.values()))
+    for fused in (True, False):
+        key_state.capacity = max(1024, R0 // 3)                  # far too small for the next frame
+        before = rz.reissued_frames(gpu_device, P, cam.image_width, cam.image_height)
+        pkg, g = _step(model, cam, bg, target, fused)            # overflows on the device, is re-issued, then runs its backward
+        assert rz.reissued_frames(gpu_device, P, cam.image_width, cam.image_height) == before + 1
+        assert rz.frame_counts(pkg["render"])[0] == R0
+        assert torch.equal(pkg["render"], pkg_ref["render"]) and torch.equal(pkg["radii"], pkg_ref["radii"])
+        if fused:
+            for a, b in zip(g, g_ref):
+                assert torch.equal(a, b)
+        assert key_state.capacity >= int(1.5 * R0)               # ... and the capacity has grown for the frames after it
+    # forward-only frames too (they share workspaces from frame to frame: the re-issue must not leave a stale set behind)
+    from mvs_gaussian_splatting_amd import render
+    from mvs_gaussian_splatting_amd.synthetic import PipelineParams
+    with torch.no_grad():
+        a = render(cam, model, PipelineParams(), bg)["render"]
+        key_state.capacity = max(1024, R0 // 3)
+        b = render(cam, model, PipelineParams(), bg)["render"]
+        c = render(cam, model, PipelineParams(), bg)["render"]
+    for img in (a, b, c):
+        assert torch.equal(img, pkg_ref["render"].detach())
+
+
+def test_any_camera_sequence_is_bit_identical_to_the_per_frame_readback(gpu_device, fresh_state):
+    """train.py:81-92 draws a different camera every iteration: the capacity learnt on one view says nothing about the
+    next.  Four orbit views, visited in an order that makes the instance count jump, with a capacity forced below every
+    view's count half of the time: image, radii, every gradient and the densification statistics of every step equal the
+    two-call path's bit for bit, and nothing raises."""
+    from mvs_gaussian_splatting_amd import add_densification_stats
+    rz = fresh_state
+    model, _, bg, target = _scene(gpu_device, P=8000)
+    cams = [c.to(gpu_device) for c in _views(8000)]
+    order = [0, 2, 1, 3, 3, 0, 2, 2, 1]
+
+    def run(mode, squeeze):
+        rz.set_sync_free(mode)
+        rz._states.clear()
+        model.xyz_gradient_accum.zero_(); model.denom.zero_(); model.max_radii2D.zero_()
+        out = []
+        for i, v in enumerate(order):
+            if squeeze and i % 2 == 1:
+                for st in rz._states.values():
+                    st.capacity = 2048
+            pkg, g = _step(model, cams[v], bg, target)
+            add_densification_stats(model, pkg["viewspace_points"], pkg["radii"])
+            out.append((pkg["render"].detach().clone(), pkg["radii"].clone(), g, rz.frame_counts(pkg["render"])))
+        stats = (model.xyz_gradient_accum.clone(), model.denom.clone(), model.max_radii2D.clone())
+        return out, stats
+
+    ref, ref_stats = run(False, False)
+    counts = [r[3][0] for r in ref]
+    assert len(set(counts)) >= 3 and min(counts) > 0, counts      # the views really differ
+    for squeeze in (False, True):
+        got, got_stats = run(True, squeeze)
+        for (img, radii, g, cnt), (img0, radii0, g0, cnt0) in zip(got, ref):
+            assert cnt == cnt0 and torch.equal(img, img0) and torch.equal(radii, radii0)
+            for a, b in zip(g, g0):
+                assert torch.equal(a, b)
+        for a, b in zip(got_stats, ref_stats):
+            assert torch.equal(a, b)
+    P = model._xyz.shape[0]
+    assert rz.reissued_frames(gpu_device, P, cams[0].image_width, cams[0].image_height) >= 4
+
+
+def test_deferred_mode_reports_an_overflow_instead_of_rendering_it_silently(gpu_device, fresh_state):
+    rz = fresh_state
+    rz.set_sync_free("deferred")
     model, cam, bg, target = _scene(gpu_device)
     pkg0, _ = _step(model, cam, bg, target)
     R0, _ = rz.frame_counts(pkg0["render"])
