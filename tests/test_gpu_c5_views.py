@@ -10,7 +10,7 @@ the camera rotated by 45 deg * v about the cloud centre), each at full size (192
   ``test_gpu_parity.py``): sortedness, ties in index order, ranges partition the list, one instance per overlapped tile,
   sum(w) + T_final = 1, culled == un-culled pixels, run-to-run determinism.
 
-The masked float64 comparison of a rotated view is ``test_gpu_parity.py::test_config_C4_masked_train_step_matches_fp64_oracle[3]``.
+The masked float64 comparison of a rotated view is ``test_gpu_parity.py::test_config_C4_masked_train_step_matches_fp64_oracle[2]``.
 """
 import numpy as np
 import pytest
