@@ -264,6 +264,53 @@ __global__ __launch_bounds__(256) void reconstruct_keys_kernel(uint32_t R, uint3
 // Item order inside a block tile: wave w owns [w*1024, w*1024+1024); item i of lane l is
 // element i*64 + l of that range, so (i, l) lexicographic == memory order (stability).
 // ------------------------------------------------------------------------------------------
+// ---- segmented pass ------------------------------------------------------------------------------------------------
+// The LAST pass of a two-pass sort can have its blocks aligned with the SEGMENTS the first pass left behind (segment L =
+// the run of items whose first digit is L, lengths = the first pass's digit totals): block b then holds items of ONE
+// first digit only, so the exclusive row prefixes of its histogram matrix ARE the boundaries of every full key's run --
+// the tile ranges of the binning fall out of the sort (ranges_from_hist_kernel) and no pass over the sorted keys
+// (identifyTileRanges) nor a memset is needed.  Costs ~one partial block per segment.
+struct SegBlock { uint32_t base, count, nblocks; bool valid; };
+// blocks of a segment of n items
+__device__ inline uint32_t seg_blocks_of(uint32_t n) { return (n + (uint32_t)SORT_TILE - 1u) / (uint32_t)SORT_TILE; }
+// (first item, item count) of block b and the number of blocks in use; every lane of the calling wave gets the result.
+// seg_count <= 512 segments, eight per lane.
+__device__ inline SegBlock seg_block(const uint32_t* __restrict__ seg_totals, int seg_count, uint32_t b) {
+  const int lane = lane_id();
+  uint32_t cnt[8], items = 0, blocks = 0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int sgm = lane * 8 + u;
+    cnt[u] = sgm < seg_count ? seg_totals[sgm] : 0u;
+    items += cnt[u];
+    blocks += seg_blocks_of(cnt[u]);
+  }
+  const uint32_t item_inc = wave_incl_scan_u32(items), blk_inc = wave_incl_scan_u32(blocks);
+  SegBlock r;
+  r.nblocks = (uint32_t)__shfl((int)blk_inc, WAVE - 1, WAVE);
+  r.valid = b < r.nblocks;
+  r.base = 0; r.count = 0;
+  // the lane whose eight segments hold block b
+  const unsigned long long owner = __ballot(b >= blk_inc - blocks && b < blk_inc);
+  if (owner) {
+    const int src = __ffsll((long long)owner) - 1;
+    uint32_t ib = item_inc - items, bb = blk_inc - blocks, base = 0, count = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const uint32_t nb = seg_blocks_of(cnt[u]);
+      if (b >= bb && b < bb + nb) {
+        const uint32_t off = (b - bb) * (uint32_t)SORT_TILE;
+        base = ib + off;
+        count = min((uint32_t)SORT_TILE, cnt[u] - off);
+      }
+      ib += cnt[u]; bb += nb;
+    }
+    r.base = (uint32_t)__shfl((int)base, src, WAVE);
+    r.count = (uint32_t)__shfl((int)count, src, WAVE);
+  }
+  return r;
+}
+
 template <typename KeyT>
 __device__ inline uint32_t digit_of(KeyT k, int shift, uint32_t mask) { return (uint32_t)(k >> shift) & mask; }
 
@@ -271,18 +318,25 @@ template <typename KeyT, int BITS, int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT* __restrict__ keys, uint32_t n,
                                                                   const uint32_t* __restrict__ n_dev, int shift,
                                                                   uint32_t mask, uint32_t nblocks,
-                                                                  uint32_t* __restrict__ hist) {
+                                                                  uint32_t* __restrict__ hist,
+                                                                  const uint32_t* __restrict__ seg_totals = nullptr,
+                                                                  int seg_count = 0) {
   constexpr int RADIX = 1 << BITS;
   __shared__ uint32_t h[RADIX];
   if (n_dev) n = *n_dev;     // element count known only on the device (grid sized for the capacity)
-  if (blockIdx.x * (SORT_THREADS * ITEMS) >= n) return;   // block past the count (grid sized for a capacity; n == 0: a
+  uint32_t base = blockIdx.x * (SORT_THREADS * ITEMS);
+  if (seg_totals) {
+    const SegBlock sb = seg_block(seg_totals, seg_count, blockIdx.x);
+    if (!sb.valid) return;
+    base = sb.base;
+    n = sb.base + sb.count;
+  } else if (base >= n) return;                           // block past the count (grid sized for a capacity; n == 0: a
                                                            // predicated pass that does not run) -- rowscan and scatter skip
                                                            // the same columns
   const int tid = threadIdx.x;
 #pragma unroll
   for (int d = tid; d < RADIX; d += SORT_THREADS) h[d] = 0;
   __syncthreads();
-  const uint32_t base = blockIdx.x * (SORT_THREADS * ITEMS);
   KeyT kk[ITEMS];
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {       // all loads in flight before the first LDS atomic
@@ -303,11 +357,45 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT* __
 // loads), the block scans the 256 lane sums, the lane writes its 8 prefixes back
 __global__ __launch_bounds__(256) void radix_rowscan_kernel(uint32_t* __restrict__ hist, uint32_t nblocks,
                                                             uint32_t* __restrict__ totals,
-                                                            const uint32_t* __restrict__ n_dev) {
+                                                            const uint32_t* __restrict__ n_dev,
+                                                            const uint32_t* __restrict__ seg_totals = nullptr,
+                                                            int seg_count = 0, uint2* __restrict__ runs_rel = nullptr,
+                                                            int lo_bits = 0, uint32_t n_keys = 0) {
   constexpr uint32_t PER = 8;
   __shared__ uint32_t wave_tot[256 / WAVE];
+  __shared__ uint32_t seg_first[RADIX + 1];    // segmented pass: first block of every segment; [seg_count] = blocks in use
   const uint32_t stride = nblocks;
-  if (n_dev) {
+  if (seg_totals) {           // segmented pass: the columns in use are the blocks its segments need
+    if (threadIdx.x < WAVE) {
+      uint32_t b8[8], bs = 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int sgm = (int)threadIdx.x * 8 + u;
+        b8[u] = sgm < seg_count ? seg_blocks_of(seg_totals[sgm]) : 0u;
+        bs += b8[u];
+      }
+      uint32_t br = wave_incl_scan_u32(bs) - bs;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int sgm = (int)threadIdx.x * 8 + u;
+        if (sgm < seg_count) seg_first[sgm] = br;
+        br += b8[u];
+      }
+      if (threadIdx.x == WAVE - 1) seg_first[seg_count] = br;     // the blocks in use (seg_count may be 512 = 64 x 8)
+    }
+    __syncthreads();
+    nblocks = min(nblocks, seg_first[seg_count]);
+    if (nblocks == 0) {
+      // no item at all: every run of this row is empty
+      if (runs_rel)
+        for (int sgm = threadIdx.x; sgm < seg_count; sgm += 256) {
+          const uint32_t key = ((uint32_t)blockIdx.x << lo_bits) | (uint32_t)sgm;
+          if (key < n_keys) runs_rel[key] = make_uint2(0u, 0u);
+        }
+      if (threadIdx.x == 0) totals[blockIdx.x] = 0;
+      return;
+    }
+  } else if (n_dev) {
     const uint32_t n = *n_dev;
     if (n == 0) return;
     nblocks = min(nblocks, (n + SORT_TILE - 1) / SORT_TILE);   // columns past the device-side count are never written or read
@@ -357,17 +445,39 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(uint32_t* __restrict
     carry += all;
   }
   if (tid == 0) totals[blockIdx.x] = carry;
+  if (runs_rel) {
+    // Segmented pass: the items of key (this row's digit << lo_bits | L) are those this row counts in the blocks of
+    // segment L, so the key's run starts, relative to the row's first item, at the row prefix of the segment's first
+    // block and ends at the prefix of the next segment's first block -- both just written.  (__syncthreads makes the
+    // block's own global stores visible to it.)
+    __syncthreads();
+    for (int sgm = tid; sgm < seg_count; sgm += 256) {
+      const uint32_t key = ((uint32_t)blockIdx.x << lo_bits) | (uint32_t)sgm;
+      if (key < n_keys) {
+        const uint32_t b0 = seg_first[sgm], b1 = seg_first[sgm + 1];
+        const uint32_t x = b0 < nblocks ? row[b0] : carry, y = b1 < nblocks ? row[b1] : carry;
+        runs_rel[key] = make_uint2(x, y);
+      }
+    }
+  }
 }
 
 template <typename KeyT, typename ValT, int BITS, int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const KeyT* __restrict__ keys_in, const ValT* __restrict__ vals_in, KeyT* __restrict__ keys_out,
     ValT* __restrict__ vals_out, uint32_t n, const uint32_t* __restrict__ n_dev, int shift, uint32_t mask,
-    uint32_t nblocks, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals) {
+    uint32_t nblocks, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals,
+    const uint32_t* __restrict__ seg_totals = nullptr, int seg_count = 0) {
   constexpr int RADIX = 1 << BITS;
   constexpr int NW = SORT_THREADS / WAVE;
   if (n_dev) n = *n_dev;
-  if (blockIdx.x * (SORT_THREADS * ITEMS) >= n) return;   // block beyond the device-side count (uniform: no barrier crossed)
+  uint32_t base = blockIdx.x * (SORT_THREADS * ITEMS);
+  if (seg_totals) {                                        // segmented pass: see seg_block
+    const SegBlock sb = seg_block(seg_totals, seg_count, blockIdx.x);
+    if (!sb.valid) return;
+    base = sb.base;
+    n = sb.base + sb.count;                                // the block's items end where its segment (or its 4096) ends
+  } else if (base >= n) return;   // block beyond the device-side count (uniform: no barrier crossed)
   using WideT = typename std::conditional<(sizeof(ValT) > sizeof(KeyT)), ValT, KeyT>::type;
   __shared__ WideT xbuf_w[(SORT_THREADS * ITEMS)];         // exchange buffer: keys first, then reused for the values
   KeyT* xbuf = reinterpret_cast<KeyT*>(xbuf_w);
@@ -377,7 +487,6 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
   __shared__ uint32_t scan_tmp[NW];
 
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
-  const uint32_t base = blockIdx.x * (SORT_THREADS * ITEMS);
   const uint32_t wbase = base + wid * (WAVE * ITEMS);
 
 #pragma unroll
@@ -625,6 +734,120 @@ __global__ __launch_bounds__(1024) void build_tile_order_kernel(int tiles, const
   }
 }
 
+// Two-level binning: tile ranges AND tile order from what the tile sort left behind (one block, no pass over the keys,
+// no memset).
+//   one-pass sort (at most 512 tiles): ranges[t] = (digit_base[t], digit_base[t + 1]), digit_base = exclusive scan of
+//     the digit totals;
+//   two-pass sort with a segmented last pass (seg_block): the row scan of that pass left in ranges[t] the run of tile
+//     t = hi << lo_bits | lo RELATIVE to the first item with top digit hi; adding digit_base[hi] completes it.
+// An empty tile gets (0, 0), as in the zero-filled array upstream's identifyTileRanges writes into.
+__global__ __launch_bounds__(1024) void ranges_and_order_from_sort_kernel(int tiles, const uint32_t* __restrict__ totals_last,
+                                                                          int lo_bits, int hi_bits, bool relative,
+                                                                          uint2* __restrict__ ranges,
+                                                                          uint32_t* __restrict__ order) {
+  constexpr int CHUNK = 8 * 1024;
+  __shared__ uint32_t cnt[256];
+  __shared__ uint32_t base[256];
+  __shared__ uint8_t s_code[CHUNK];
+  __shared__ uint32_t digit_base[RADIX + 1];   // exclusive scan of the last pass's digit totals
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int nhi = 1 << hi_bits;
+  // the first chunk's relative runs are requested before the scan of the totals: one trip to memory for both
+  uint2 r[8];
+  {
+    const int t_lo = tid * 8;
+    if (relative && t_lo + 8 <= tiles) {
+      const uint4* src = reinterpret_cast<const uint4*>(ranges + t_lo);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint4 q = src[u];
+        r[2 * u] = make_uint2(q.x, q.y); r[2 * u + 1] = make_uint2(q.z, q.w);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r[u] = (relative && t_lo + u < tiles) ? ranges[t_lo + u] : make_uint2(0u, 0u);
+    }
+  }
+  if (tid < WAVE) {
+    uint32_t t8[8], ts = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int d = tid * 8 + u;
+      t8[u] = d < nhi ? totals_last[d] : 0u;
+      ts += t8[u];
+    }
+    uint32_t tr = wave_incl_scan_u32(ts) - ts;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int d = tid * 8 + u;
+      if (d < nhi) digit_base[d] = tr;
+      tr += t8[u];
+    }
+    if (tid == WAVE - 1) digit_base[nhi] = tr;      // nhi may be 512 = 64 x 8
+  }
+  __syncthreads();
+  for (int c0 = 0; c0 < tiles; c0 += CHUNK) {
+    const int t_lo = c0 + tid * 8;        // eight consecutive tiles per thread
+    if (c0 > 0) {
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r[u] = (relative && t_lo + u < tiles) ? ranges[t_lo + u] : make_uint2(0u, 0u);
+    }
+    if (tid < 256) cnt[tid] = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = t_lo + u;
+      uint32_t x = 0, y = 0;
+      if (t < tiles) {
+        if (!relative) { x = digit_base[t]; y = digit_base[t + 1]; }
+        else { const uint32_t db = digit_base[(uint32_t)t >> lo_bits]; x = db + r[u].x; y = db + r[u].y; }
+      }
+      r[u] = y > x ? make_uint2(x, y) : make_uint2(0u, 0u);
+      s_code[tid * 8 + u] = (uint8_t)(255u - len_bucket(r[u].y - r[u].x));
+    }
+    if (t_lo + 8 <= tiles) {
+      uint4* dst = reinterpret_cast<uint4*>(ranges + t_lo);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dst[u] = make_uint4(r[2 * u].x, r[2 * u].y, r[2 * u + 1].x, r[2 * u + 1].y);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (t_lo + u < tiles) ranges[t_lo + u] = r[u];
+    }
+    __syncthreads();
+    const int n = min(CHUNK, tiles - c0);
+    for (int t0 = 0; t0 < n; t0 += 1024) {
+      const int t = t0 + tid;
+      const bool ok = t < n;
+      const uint32_t code = s_code[t0 + tid];
+      const unsigned long long peers = match8(code, ok);
+      if (ok && (peers & lt) == 0ull) atomicAdd(&cnt[code], (uint32_t)__popcll(peers));     // one atomic per group
+    }
+    __syncthreads();
+    if (tid < WAVE) {     // exclusive scan of the 256 bucket sizes by one wave (4 per lane)
+      uint32_t b[4], m4 = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { b[k] = cnt[4 * tid + k]; m4 += b[k]; }
+      uint32_t rr = wave_incl_scan_u32(m4) - m4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { base[4 * tid + k] = rr; rr += b[k]; }
+    }
+    __syncthreads();
+    for (int t0 = 0; t0 < n; t0 += 1024) {
+      const int t = t0 + tid;
+      const bool ok = t < n;
+      const uint32_t code = s_code[t0 + tid];
+      const unsigned long long peers = match8(code, ok);
+      uint32_t first = 0;
+      const int leader = __ffsll((long long)peers) - 1;
+      if (ok && lane == leader) first = atomicAdd(&base[code], (uint32_t)__popcll(peers));
+      first = (uint32_t)__shfl((int)first, leader, WAVE);
+      if (ok) order[c0 + first + (uint32_t)__popcll(peers & lt)] = (uint32_t)(c0 + t);
+    }
+  }
+}
+
 void launch_duplicate_with_keys(int P, int grid_x, const BinInfo* bin, const uint32_t* block_offs, uint32_t* slot_base,
                                 uint32_t* point_offsets, uint64_t* keys, uint32_t* vals, hipStream_t s) {
   const int nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
@@ -635,17 +858,21 @@ void launch_duplicate_with_keys(int P, int grid_x, const BinInfo* bin, const uin
 
 template <typename KeyT, typename ValT, int BITS>
 static void sort_pass(const KeyT* kin, const ValT* vin, KeyT* kout, ValT* vout, uint32_t n, const uint32_t* n_dev,
-                      int shift, int nbits, const SortLayout& L, uint32_t* hist, uint32_t* totals, hipStream_t s) {
+                      int shift, int nbits, const SortLayout& L, uint32_t* hist, uint32_t* totals, hipStream_t s,
+                      const uint32_t* seg_totals = nullptr, int seg_count = 0, uint2* runs_rel = nullptr,
+                      int lo_bits = 0, uint32_t n_keys = 0) {
   const uint32_t mask = (1u << nbits) - 1u;      // nbits <= BITS: digits above the mask do not occur
   // (8192-item tiles for 32-bit keys were measured: no gain once the digits are <= 8 bits wide)
   constexpr int ITEMS = SORT_ITEMS;
-  const uint32_t nblocks = (n + SORT_THREADS * ITEMS - 1) / (SORT_THREADS * ITEMS);
+  // a segmented pass needs up to one partial block per segment more (SortLayout reserves the columns)
+  const uint32_t nblocks = (n + SORT_THREADS * ITEMS - 1) / (SORT_THREADS * ITEMS) + (seg_totals ? (uint32_t)seg_count : 0u);
   (void)L;
   hipLaunchKernelGGL((radix_hist_kernel<KeyT, BITS, ITEMS>), dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, n, n_dev, shift,
-                     mask, nblocks, hist);
-  hipLaunchKernelGGL(radix_rowscan_kernel, dim3(1 << BITS), dim3(256), 0, s, hist, nblocks, totals, n_dev);
+                     mask, nblocks, hist, seg_totals, seg_count);
+  hipLaunchKernelGGL(radix_rowscan_kernel, dim3(1 << BITS), dim3(256), 0, s, hist, nblocks, totals, n_dev, seg_totals,
+                     seg_count, runs_rel, lo_bits, n_keys);
   hipLaunchKernelGGL((radix_scatter_kernel<KeyT, ValT, BITS, ITEMS>), dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, vin, kout,
-                     vout, n, n_dev, shift, mask, nblocks, hist, totals);
+                     vout, n, n_dev, shift, mask, nblocks, hist, totals, seg_totals, seg_count);
 }
 
 // Digit widths of the passes.  A block scatters 4096 items: with 2^w digits a digit's run leaves the block as
@@ -659,27 +886,47 @@ int sort_pass_plan(int end_bit, int widths[8]) {
   return passes;
 }
 
-// n = element count, or the capacity when n_dev (device-side count) is given
+// n = element count, or the capacity when n_dev (device-side count) is given.
+// runs != NULL (one- and two-pass sorts only): the last pass is segmented and *runs describes where every key's run lies.
 template <typename KeyT, typename ValT>
 static bool sort_pairs_impl(KeyT* keys_a, ValT* vals_a, KeyT* keys_b, ValT* vals_b, uint32_t n, int end_bit,
-                            void* scratch, hipStream_t s, const uint32_t* n_dev = nullptr) {
+                            void* scratch, hipStream_t s, const uint32_t* n_dev = nullptr, SortedRuns* runs = nullptr) {
+  if (runs) runs->valid = false;
   if (n == 0 || end_bit <= 0) return false;
+  // the rows of a segmented pass write one relative run per key value: every row must exist in the launch, i.e. the last
+  // digit's kernels are instantiated for exactly its width -- true for the 6..9-bit kernels; narrower last digits run the
+  // 6-bit kernels, whose 64 rows cover them
   const SortLayout L(n);
   uint32_t* hist = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + L.hist);
-  uint32_t* totals = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + L.totals);
+  uint32_t* totals_pp[2] = {reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + L.totals),
+                            reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + L.totals_odd)};
   int widths[8];
   const int passes = sort_pass_plan(end_bit, widths);
   KeyT* kin = keys_a; ValT* vin = vals_a; KeyT* kout = keys_b; ValT* vout = vals_b;
   int shift = 0;
   for (int pass = 0; pass < passes; ++pass) {
     const int w = widths[pass];
-    if (w <= 6)      sort_pass<KeyT, ValT, 6>(kin, vin, kout, vout, n, n_dev, shift, w, L, hist, totals, s);
-    else if (w == 7) sort_pass<KeyT, ValT, 7>(kin, vin, kout, vout, n, n_dev, shift, w, L, hist, totals, s);
-    else if (w == 8) sort_pass<KeyT, ValT, 8>(kin, vin, kout, vout, n, n_dev, shift, w, L, hist, totals, s);
-    else             sort_pass<KeyT, ValT, 9>(kin, vin, kout, vout, n, n_dev, shift, w, L, hist, totals, s);
+    uint32_t* totals = totals_pp[pass & 1];
+    const bool seg = runs && passes == 2 && pass == 1;
+    const uint32_t* st = seg ? totals_pp[0] : nullptr;
+    const int sc = seg ? 1 << widths[0] : 0;
+    uint2* rr = seg ? runs->runs_rel : nullptr;
+    const int lb = widths[0];
+    const uint32_t nk = seg ? runs->n_keys : 0u;
+    if (w <= 6)      sort_pass<KeyT, ValT, 6>(kin, vin, kout, vout, n, n_dev, shift, w, L, hist, totals, s, st, sc, rr, lb, nk);
+    else if (w == 7) sort_pass<KeyT, ValT, 7>(kin, vin, kout, vout, n, n_dev, shift, w, L, hist, totals, s, st, sc, rr, lb, nk);
+    else if (w == 8) sort_pass<KeyT, ValT, 8>(kin, vin, kout, vout, n, n_dev, shift, w, L, hist, totals, s, st, sc, rr, lb, nk);
+    else             sort_pass<KeyT, ValT, 9>(kin, vin, kout, vout, n, n_dev, shift, w, L, hist, totals, s, st, sc, rr, lb, nk);
     shift += w;
     KeyT* tk = kin; kin = kout; kout = tk;
     ValT* tv = vin; vin = vout; vout = tv;
+  }
+  if (runs && passes <= 2) {
+    runs->valid = true;
+    runs->totals_last = totals_pp[(passes - 1) & 1];
+    runs->relative = passes == 2;
+    runs->lo_bits = passes == 2 ? widths[0] : 0;
+    runs->hi_bits = widths[passes - 1];
   }
   return (passes & 1) != 0;
 }
@@ -688,8 +935,8 @@ bool launch_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uin
   return sort_pairs_impl<uint64_t, uint32_t>(keys_a, vals_a, keys_b, vals_b, n, end_bit, scratch, s);
 }
 bool launch_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n,
-                           int end_bit, void* scratch, hipStream_t s, const uint32_t* n_dev) {
-  return sort_pairs_impl<uint32_t, uint32_t>(keys_a, vals_a, keys_b, vals_b, n, end_bit, scratch, s, n_dev);
+                           int end_bit, void* scratch, hipStream_t s, const uint32_t* n_dev, SortedRuns* runs) {
+  return sort_pairs_impl<uint32_t, uint32_t>(keys_a, vals_a, keys_b, vals_b, n, end_bit, scratch, s, n_dev, runs);
 }
 bool launch_sort_pairs_u32_v64(uint32_t* keys_a, uint2* vals_a, uint32_t* keys_b, uint2* vals_b, uint32_t n,
                                int end_bit, void* scratch, hipStream_t s, const uint32_t* n_dev) {
@@ -734,6 +981,10 @@ void launch_reconstruct_keys(uint32_t R, uint32_t P, const uint32_t* tile_sorted
 
 void launch_build_tile_order(int tiles, const uint2* ranges, uint32_t* order, hipStream_t s) {
   hipLaunchKernelGGL(build_tile_order_kernel, dim3(1), dim3(1024), 0, s, tiles, ranges, order);
+}
+void launch_ranges_and_order_from_sort(int tiles, const SortedRuns& sr, uint2* ranges, uint32_t* order, hipStream_t s) {
+  hipLaunchKernelGGL(ranges_and_order_from_sort_kernel, dim3(1), dim3(1024), 0, s, tiles, sr.totals_last, sr.lo_bits,
+                     sr.hi_bits, sr.relative, ranges, order);
 }
 
 void launch_identify_tile_ranges(uint32_t R, const uint64_t* keys, uint2* ranges, hipStream_t s) {

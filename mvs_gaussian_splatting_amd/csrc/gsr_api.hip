@@ -179,7 +179,7 @@ SortedViews sorted_views(const void* bin_ws, uint32_t R, uint32_t V, int W, int 
     v.keys_sorted = at<uint64_t>(bin_ws, in_b ? B.keys_b : B.keys_a);
     v.inst_mask = reinterpret_cast<uint16_t*>(ws + (in_b ? B.vals_a : B.vals_b));
   } else {
-    const bool in_b = (sort_passes(tile_bits(I.tiles)) & 1) != 0;
+    const bool in_b = (sort_passes(tile_sort_bits(I.tiles)) & 1) != 0;
     v.point_list = at<uint32_t>(bin_ws, in_b ? B.ig_b : B.ig_a);
     v.tile_sorted = at<uint32_t>(bin_ws, in_b ? B.itile_b : B.itile_a);
     v.inst_mask = reinterpret_cast<uint16_t*>(ws + (in_b ? B.ig_a : B.ig_b));
@@ -262,7 +262,12 @@ static int enqueue_stage2(const GsrParams* p, void* geom_ws, void* bin_ws, size_
                           uint32_t r_cap, uint32_t v_cap, bool device_counts, float* out_color, hipStream_t s) {
   const ImageLayout I(p->width, p->height);
   uint2* ranges = at<uint2>(img_ws, I.ranges);
-  GSR_HIP(hipMemsetAsync(ranges, 0, 8 * (size_t)I.tiles, s));
+  // two-level modes: the ranges come out of the tile sort's own histogram (launch_ranges_and_order_from_sort: no memset,
+  // no pass over the sorted keys); 64-bit key mode, or nothing to bin: upstream's identifyTileRanges into a zero-filled array
+  SortedRuns runs;
+  runs.valid = false;
+  runs.runs_rel = ranges;
+  runs.n_keys = (uint32_t)I.tiles;
   const uint32_t* point_list = nullptr;
   uint16_t* inst_mask = nullptr;     // the sort's spare payload buffer (see SortedViews)
   const GeomRec* rec = nullptr;
@@ -278,7 +283,7 @@ static int enqueue_stage2(const GsrParams* p, void* geom_ws, void* bin_ws, size_
     rec = at<GeomRec>(geom_ws, L.rec);
     const BinInfo* bin = at<BinInfo>(geom_ws, L.bin);
     const uint32_t* total = at<uint32_t>(geom_ws, L.total);
-    const int tb = tile_bits(I.tiles);
+    const int tb = mode == GSR_BINNING_KEYS64 ? tile_bits(I.tiles) : tile_sort_bits(I.tiles);
     if (mode == GSR_BINNING_KEYS64) {
       if (device_counts) return fail(GSR_E_BADARG, "gsr_forward supports the two-level binning modes only");
       uint64_t* ka = at<uint64_t>(bin_ws, B.keys_a);
@@ -299,6 +304,7 @@ static int enqueue_stage2(const GsrParams* p, void* geom_ws, void* bin_ws, size_
       if (int rc = check(p, s, "sort_pairs")) return rc;
       {
         StageTimer t(p, GSR_STAGE_RANGES, s);
+        GSR_HIP(hipMemsetAsync(ranges, 0, 8 * (size_t)I.tiles, s));
         launch_identify_tile_ranges(r_cap, in_b ? kb : ka, ranges, s);
       }
       point_list = in_b ? vb : va;
@@ -326,19 +332,26 @@ static int enqueue_stage2(const GsrParams* p, void* geom_ws, void* bin_ws, size_
       bool in_b;
       {
         StageTimer t(p, GSR_STAGE_SORT, s);     // stable partition by tile id
-        in_b = launch_sort_pairs_u32(ita, iga, itb, igb, r_cap, tb, at<char>(bin_ws, B.sort), s, r_dev);
+        in_b = launch_sort_pairs_u32(ita, iga, itb, igb, r_cap, tb, at<char>(bin_ws, B.sort), s, r_dev, &runs);
       }
       if (int rc = check(p, s, "tile_sort")) return rc;
-      {
+      if (!runs.valid) {       // more than 2^18 tiles: three passes -- read the ranges off the sorted keys
         StageTimer t(p, GSR_STAGE_RANGES, s);
+        GSR_HIP(hipMemsetAsync(ranges, 0, 8 * (size_t)I.tiles, s));
         launch_identify_tile_ranges_u32(r_cap, in_b ? itb : ita, ranges, s, r_dev);
       }
       point_list = in_b ? igb : iga;
       inst_mask = reinterpret_cast<uint16_t*>(in_b ? iga : igb);
     }
     if (int rc = check(p, s, "identify_tile_ranges")) return rc;
+  } else {
+    GSR_HIP(hipMemsetAsync(ranges, 0, 8 * (size_t)I.tiles, s));      // nothing to bin: every tile is empty
   }
-  launch_build_tile_order(I.tiles, ranges, at<uint32_t>(img_ws, I.tile_order), s);
+  {
+    StageTimer t(p, GSR_STAGE_RANGES, s);
+    if (runs.valid) launch_ranges_and_order_from_sort(I.tiles, runs, ranges, at<uint32_t>(img_ws, I.tile_order), s);
+    else launch_build_tile_order(I.tiles, ranges, at<uint32_t>(img_ws, I.tile_order), s);
+  }
   {
     StageTimer t(p, GSR_STAGE_RENDER_FWD, s);
     const bool track = !p->forward_only;

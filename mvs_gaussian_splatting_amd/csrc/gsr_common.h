@@ -112,6 +112,27 @@ constexpr int PRE_BLOCK = 256;      // Gaussians per preprocess / duplicate bloc
                                     // hierarchical scan lines up)
 
 // ---- workspace layouts (host + device agree through these helpers) -------------------------
+constexpr int SORT_THREADS = 512;
+constexpr int SORT_ITEMS = 8;
+constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;   // keys per sort block
+constexpr int RADIX_BITS = 9;   // widest digit: 45-bit keys at 1080p (13 tile bits + 32 depth bits) sort in 5 passes
+constexpr int RADIX = 1 << RADIX_BITS;
+
+struct SortLayout {
+  size_t hist, totals, totals_odd, bytes;
+  uint32_t nblocks;
+  __host__ __device__ explicit SortLayout(uint32_t n) {
+    nblocks = (n + SORT_TILE - 1) / SORT_TILE;
+    if (nblocks == 0) nblocks = 1;
+    nblocks += RADIX;          // a segmented last pass (binning.hip: seg_block) has up to one partial block per segment more
+    size_t o = 0;
+    hist = o;   o = align_up(o + 4 * (size_t)RADIX * nblocks, 256);
+    totals = o; o = align_up(o + 4 * (size_t)RADIX, 256);        // digit totals of passes 0, 2, ...
+    totals_odd = o; o = align_up(o + 4 * (size_t)RADIX, 256);    // ... and of passes 1, 3, ...: a segmented pass reads the
+    bytes = o;                                                   //     totals of the pass before it while writing its own
+  }
+};
+
 struct GeomLayout {
   size_t rec, bin, offsets, slot_base, block_sums, block_offs, block_vis, block_vis_offs, block_range, total;
   size_t dkey_a, dkey_b, didx_a, didx_b, dsort, big_list, bytes;   // depth sort of the visible Gaussians (capacity P)
@@ -133,7 +154,7 @@ struct GeomLayout {
     dkey_b = o;     o = align_up(o + 4 * (size_t)P, 256);
     didx_a = o;     o = align_up(o + 8 * (size_t)P, 256);    // payload: (index, packed rect)
     didx_b = o;     o = align_up(o + 8 * (size_t)P, 256);
-    dsort = o;      o = align_up(o + 4 * (size_t)(1 << 9) * ((size_t)P / 4096 + 2) + 4096, 256);
+    dsort = o;      o = align_up(o + SortLayout((uint32_t)(P > 0 ? P : 1)).bytes, 256);
     big_list = o;   o = align_up(o + 4 * (size_t)P, 256);    // Gaussians with more than ROWS_COOP instances (any order)
     bytes = o;
   }
@@ -165,25 +186,6 @@ struct ImageLayout {
     ranges = o;    o = align_up(o + 8 * (size_t)tiles, 256);
     tile_max = o;  o = align_up(o + 4 * (size_t)tiles, 256);
     tile_order = o; o = align_up(o + 4 * (size_t)tiles, 256);   // tiles, longest list first
-    bytes = o;
-  }
-};
-
-constexpr int SORT_THREADS = 512;
-constexpr int SORT_ITEMS = 8;
-constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;   // keys per sort block
-constexpr int RADIX_BITS = 9;   // widest digit: 45-bit keys at 1080p (13 tile bits + 32 depth bits) sort in 5 passes
-constexpr int RADIX = 1 << RADIX_BITS;
-
-struct SortLayout {
-  size_t hist, totals, bytes;
-  uint32_t nblocks;
-  __host__ __device__ explicit SortLayout(uint32_t n) {
-    nblocks = (n + SORT_TILE - 1) / SORT_TILE;
-    if (nblocks == 0) nblocks = 1;
-    size_t o = 0;
-    hist = o;   o = align_up(o + 4 * (size_t)RADIX * nblocks, 256);
-    totals = o; o = align_up(o + 4 * (size_t)RADIX, 256);
     bytes = o;
   }
 };
@@ -240,6 +242,10 @@ __host__ __device__ inline int tile_bits(int tiles) {
   while ((1 << b) < tiles) ++b;   // ceil(log2 T): upstream getHigherMsb equivalent for the sort range
   return b;
 }
+
+// key bits of the two-level binning's tile sort: at least one, so that a pass always runs (a one-tile image too) and the
+// digit totals, from which the tile ranges are derived, exist
+__host__ __device__ inline int tile_sort_bits(int tiles) { const int b = tile_bits(tiles); return b < 1 ? 1 : b; }
 
 // Smallest value of q(d) = cxx dx^2 + 2 cxy dx dy + cyy dy^2 over the rectangle [x0,x1] x [y0,y1] of offsets
 // d = p - mean.  q is convex with its minimum (0) at the mean: inside the rectangle the answer is 0, otherwise the

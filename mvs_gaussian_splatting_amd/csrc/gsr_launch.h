@@ -27,14 +27,28 @@ void launch_duplicate_with_keys(int P, int grid_x, const BinInfo* bin, const uin
 bool launch_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, uint32_t n,
                        int end_bit, void* scratch, hipStream_t s);
 // n_dev != NULL: the element count is read from device memory and n is the capacity the grid is sized for
+// In / out of a sort that also delivers where every key value's run lies in the sorted array, without a pass over it
+// (binning.hip: seg_block, radix_rowscan_kernel, ranges_and_order_from_sort_kernel).
+struct SortedRuns {
+  uint2* runs_rel;               // in: [n_keys] array the last pass's row scan writes RELATIVE runs into (two-pass sorts)
+  uint32_t n_keys;               // in: number of key values (tiles)
+  bool valid;                    // out: false = more than two passes (use identify_tile_ranges)
+  bool relative;                 // out: runs_rel was written (two passes); false: one pass, the runs are the digit totals' scan
+  const uint32_t* totals_last;   // out: digit totals of the last pass
+  int lo_bits, hi_bits;          // out: digit widths of the first / last pass (lo_bits = 0: one pass)
+};
+// runs != NULL: sorts of at most two passes run their last pass segmented and fill *runs
 bool launch_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n,
-                           int end_bit, void* scratch, hipStream_t s, const uint32_t* n_dev = nullptr);
+                           int end_bit, void* scratch, hipStream_t s, const uint32_t* n_dev = nullptr,
+                           SortedRuns* runs = nullptr);
 // r_dev != NULL: the instance count is read from device memory and R is the capacity the grid is sized for
 void launch_identify_tile_ranges_u32(uint32_t R, const uint32_t* tiles, uint2* ranges, hipStream_t s,
                                      const uint32_t* r_dev = nullptr);
 inline int sort_passes(int end_bit) { return (end_bit + RADIX_BITS - 1) / RADIX_BITS; }
 void launch_identify_tile_ranges(uint32_t R, const uint64_t* keys, uint2* ranges, hipStream_t s);
 void launch_build_tile_order(int tiles, const uint2* ranges, uint32_t* order, hipStream_t s);
+// two-level binning: tile ranges ((0,0) for empty tiles) from the tile sort's histogram + the tile order, one kernel
+void launch_ranges_and_order_from_sort(int tiles, const SortedRuns& sr, uint2* ranges, uint32_t* order, hipStream_t s);
 // also derives the device-side counts of the later stages (GeomLayout::total[TOTAL_TOP_PASS_N / TOTAL_R_CLAMPED]);
 // capacity: instances the binning workspace holds (0xffffffff when the host sizes it from the real count)
 void launch_compact_visible(int P, const BinInfo* bin, const uint32_t* block_vis_offs, const uint32_t* block_offs,

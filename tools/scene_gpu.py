@@ -5,7 +5,7 @@ import math
 import torch
 
 from mvs_gaussian_splatting_amd import _lib
-from mvs_gaussian_splatting_amd.rasterizer import GaussianRasterizationSettings, _make_params, _counts_pinned_two_call
+from mvs_gaussian_splatting_amd.rasterizer import GaussianRasterizationSettings, _make_params, _counts_pinned_thread
 from mvs_gaussian_splatting_amd.synthetic import CONFIGS, make_scene
 
 
@@ -38,7 +38,7 @@ class GpuScene:
         else:
             self.params, self.keep = _make_params(dev, self.settings, *self.inputs)
         self.stream = torch.cuda.current_stream(dev).cuda_stream
-        self.pinned = _counts_pinned_two_call()
+        self.pinned = _counts_pinned_thread()[0]
         self.params.counts_pinned = self.pinned.data_ptr()
         lib = self.lib
         self.geom = torch.empty(lib.gsr_geom_bytes(self.P), dtype=torch.uint8, device=dev)

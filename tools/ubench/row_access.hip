@@ -21,6 +21,77 @@ __device__ inline bool visible(uint32_t i, uint32_t pct) {
   return (h % 100u) < pct;
 }
 
+typedef float v4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float v4a __attribute__((ext_vector_type(4)));
+
+// R4 / R5 / R7: row per lane with explicit 16-byte pieces.  NT_LOAD: nontemporal row loads; NT_STORE: nontemporal stores
+// of the record / BinInfo / radius; PER: Gaussians per lane (the second one 256 further on: both rows' loads in flight)
+template <bool NT_LOAD, bool NT_STORE, int PER>
+__global__ __launch_bounds__(256) void k2(int P, const float* __restrict__ xyz, const float* __restrict__ scl,
+                                          const float4* __restrict__ rot, const float* __restrict__ opa,
+                                          const float* __restrict__ fdc, const float* __restrict__ frest,
+                                          Rec* __restrict__ rec, float4* __restrict__ bin, int* __restrict__ radii,
+                                          uint32_t pct) {
+  float acc[PER];
+  bool vis[PER];
+  float f[PER][48];
+  int idx[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    idx[u] = (blockIdx.x * PER + u) * 256 + threadIdx.x;
+    acc[u] = 0.f; vis[u] = false;
+    if (idx[u] < P) {
+      const size_t i = idx[u];
+      const float px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+      const float s0 = scl[3 * i], s1 = scl[3 * i + 1], s2 = scl[3 * i + 2];
+      const float4 q = rot[i];
+      const float o = opa[i];
+      acc[u] = px + py + pz + s0 + s1 + s2 + q.x + q.y + q.z + q.w + o;
+      vis[u] = visible((uint32_t)i, pct) && acc[u] != 12345.6789f;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    if (vis[u]) {
+      const float* __restrict__ rr = frest + (size_t)idx[u] * ROW;
+#pragma unroll
+      for (int c = 0; c < 11; ++c) {
+        const v4u v = NT_LOAD ? __builtin_nontemporal_load(reinterpret_cast<const v4u*>(rr + 4 * c))
+                              : *reinterpret_cast<const v4u*>(rr + 4 * c);
+        f[u][3 + 4 * c] = v.x; f[u][4 + 4 * c] = v.y; f[u][5 + 4 * c] = v.z; f[u][6 + 4 * c] = v.w;
+      }
+      f[u][47] = NT_LOAD ? __builtin_nontemporal_load(rr + 44) : rr[44];
+      f[u][0] = fdc[3 * (size_t)idx[u]]; f[u][1] = fdc[3 * (size_t)idx[u] + 1]; f[u][2] = fdc[3 * (size_t)idx[u] + 2];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    if (vis[u]) {
+      v4a* dst = reinterpret_cast<v4a*>(rec + idx[u]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        v4a r;
+        r.x = f[u][4 * c] + f[u][16 + 4 * c] + f[u][32 + 4 * c] + acc[u];
+        r.y = f[u][4 * c + 1] + f[u][17 + 4 * c] + f[u][33 + 4 * c] + acc[u];
+        r.z = f[u][4 * c + 2] + f[u][18 + 4 * c] + f[u][34 + 4 * c] + acc[u];
+        r.w = f[u][4 * c + 3] + f[u][19 + 4 * c] + f[u][35 + 4 * c] + acc[u];
+        if (NT_STORE) __builtin_nontemporal_store(r, dst + c); else dst[c] = r;
+      }
+    }
+    if (idx[u] < P) {
+      const int rad = vis[u] ? 3 : 0;
+      v4a b = {vis[u] ? acc[u] : 0.f, vis[u] ? 1.f : 0.f, vis[u] ? 2.f : 0.f, vis[u] ? 3.f : 0.f};
+      if (NT_STORE) {
+        __builtin_nontemporal_store(rad, radii + idx[u]);
+        __builtin_nontemporal_store(b, reinterpret_cast<v4a*>(bin + idx[u]));
+      } else {
+        radii[idx[u]] = rad;
+        *reinterpret_cast<v4a*>(bin + idx[u]) = b;
+      }
+    }
+  }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k(int P, const float* __restrict__ xyz, const float* __restrict__ scl,
                                          const float4* __restrict__ rot, const float* __restrict__ opa,
@@ -139,6 +210,27 @@ static void run(const char* name, int P, const float* xyz, const float* scl, con
          bytes / (ms * 1e-3) / 1e9, bytes / 1e9);
 }
 
+template <bool NT_LOAD, bool NT_STORE, int PER>
+static void run2(const char* name, int P, const float* xyz, const float* scl, const float4* rot, const float* opa,
+                 const float* fdc, const float* frest, Rec* rec, float4* bin, int* radii, uint32_t pct) {
+  const int grid = (P + 256 * PER - 1) / (256 * PER);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((k2<NT_LOAD, NT_STORE, PER>), dim3(grid), dim3(256), 0, 0, P, xyz, scl, rot, opa, fdc, frest, rec, bin, radii, pct);
+  hipEventRecord(e0);
+  const int reps = 20;
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k2<NT_LOAD, NT_STORE, PER>), dim3(grid), dim3(256), 0, 0, P, xyz, scl, rot, opa, fdc, frest, rec, bin, radii, pct);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  ms /= reps;
+  const double vis = P * (pct / 100.0);
+  const double bytes = 44.0 * P + (192.0 + 64.0) * vis + 20.0 * P;
+  printf("%-58s visible %3u %%: %7.4f ms  %7.1f GB/s of the bytes the frame needs (%.3f GB)\n", name, pct, ms,
+         bytes / (ms * 1e-3) / 1e9, bytes / 1e9);
+}
+
 int main(int argc, char** argv) {
   const int P = argc > 1 ? atoi(argv[1]) : 6000000;
   float *xyz, *scl, *opa, *fdc, *frest; float4 *rot, *bin; Rec* rec; int* radii;
@@ -152,6 +244,12 @@ int main(int argc, char** argv) {
     run<1>("R1 row per lane, 45 nontemporal dword loads", P, xyz, scl, rot, opa, fdc, frest, rec, bin, radii, pct);
     run<2>("R2 wave-cooperative, all 64 rows, through LDS", P, xyz, scl, rot, opa, fdc, frest, rec, bin, radii, pct);
     run<3>("R3 wave-cooperative, visible rows only, through LDS", P, xyz, scl, rot, opa, fdc, frest, rec, bin, radii, pct);
+    run2<false, false, 1>("R4 row per lane, explicit 16-byte pieces", P, xyz, scl, rot, opa, fdc, frest, rec, bin, radii, pct);
+    run2<true, false, 1>("R5 R4 + nontemporal row loads", P, xyz, scl, rot, opa, fdc, frest, rec, bin, radii, pct);
+    run2<false, true, 1>("R6 R4 + nontemporal stores", P, xyz, scl, rot, opa, fdc, frest, rec, bin, radii, pct);
+    run2<true, true, 1>("R7 R4 + nontemporal loads and stores", P, xyz, scl, rot, opa, fdc, frest, rec, bin, radii, pct);
+    run2<false, false, 2>("R8 R4, two Gaussians per lane", P, xyz, scl, rot, opa, fdc, frest, rec, bin, radii, pct);
+    run2<true, true, 2>("R9 R7, two Gaussians per lane", P, xyz, scl, rot, opa, fdc, frest, rec, bin, radii, pct);
   }
   return 0;
 }
