@@ -7,10 +7,19 @@ synthetic Gaussians, one view per GPU (weak scaling by independent views; the on
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Two timed regions, each EXACTLY K steps bracketed by barrier + torch.cuda.synchronize() and reduced with
+Two HEADLINE regions, each EXACTLY K steps bracketed by barrier + torch.cuda.synchronize() and reduced with
 MAX over ranks:  (A) forward-only render under no_grad  -> `value` (Mpixels/s, whole job);
                  (B) train step = render + L1 + backward + densification stats (+ loss all-reduce)
                      -> `ms_per_step`.
+Rank r renders view r of the eight C5 orbit views in them (one view per GPU: weak scaling; N = 8 is SURVEY §8e's partition).
+Further regions of the same protocol, reported as extra fields of the same line (never as `value`):
+  cold_*                 the first K steps after the W warm-ups, before the untimed pre-warm steps (GPU clocks still ramping);
+  *_readback_every_frame the same steps with the count read-back in every frame (GSR_SYNC_FREE=0, upstream's behaviour);
+  train_step_ms_l1_dssim the train step with the reference's real loss, 0.8 L1 + 0.2 (1 - SSIM) (train.py:99-101);
+  c5_eight_views         the EIGHT orbit views partitioned {r, r + N, ...} over the N ranks: every rank renders
+                         its 8 / N views per round -- at N = 1 the rotating-camera loop (the instance count changes from
+                         frame to frame: the capacity-based forward is exercised under a varying R);
+  per_rank_*             every rank's own forward / train ms of the headline regions (gathered).
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -169,6 +178,50 @@ def cpu_baseline(cfg, seed, budget_tiles=1024, bwd_tiles=96):
         "train_step_ms": step_s * 1e3,
     }
 
+# cycles per wave64 VALU instruction per SIMD at 8 resident waves (tools/ubench/valu_rate.hip, profiles/r02/valu_rate.txt):
+# v_fma / v_add / v_mul / v_mov / integer ops 2.4; v_exp / v_rcp / v_rsq / v_log 8.2; the rest (v_cmp, v_cndmask, v_min, v_max,
+# v_med3, v_readlane, DPP adds mixed with moves) is priced per kernel by tools/issue_mix_static.py (profiles/valu_static_mix.json)
+VALU_CYCLES_FULL, VALU_CYCLES_TRANS = 2.4, 8.2
+SIMDS = 1024
+
+
+def issue_model(valu_mix, rest_cost_cycles, t_s, clock_hz):
+    """Instruction-issue roof of a VALU-bound kernel: the SIMD cycles its vector instructions need at their measured issue
+    rates, over the SIMD cycles the launch had (1024 SIMDs x clock x duration).
+      valu_mix: per-launch wave-level counts from one rocprofv3 --pmc pass (SQ_INSTS_VALU and its ADD / MUL / FMA / TRANS /
+      INT32 / INT64 / CVT sub-counters); what the sub-counters do not name is priced at rest_cost_cycles."""
+    total = float(valu_mix.get("SQ_INSTS_VALU", 0))
+    if total <= 0 or t_s <= 0:
+        return None
+    full = sum(float(valu_mix.get(k, 0)) for k in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32",
+                                                    "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_CVT"))
+    trans = float(valu_mix.get("SQ_INSTS_VALU_TRANS_F32", 0))
+    rest = max(0.0, total - full - trans)
+    cycles = VALU_CYCLES_FULL * full + VALU_CYCLES_TRANS * trans + rest_cost_cycles * rest
+    return {"valu_insts": int(total), "full_rate": int(full), "transcendental": int(trans), "rest": int(rest),
+            "rest_cost_cycles": rest_cost_cycles, "valu_issue_cycles": int(cycles), "clock_GHz": round(clock_hz / 1e9, 3),
+            "frac_of_issue_roof": round(cycles / (SIMDS * clock_hz * t_s), 4),
+            "cycles_per_valu_inst": round(cycles / total, 3)}
+
+
+def c5_views_of_rank(rank, world, n_views=8):
+    """rank r renders views {r, r + N, ...} of the eight."""
+    from mvs_gaussian_splatting_amd.dist import views_of_rank
+    return views_of_rank(n_views, rank, world)
+
+
+def c5_summary(per_rank_fwd_s, per_rank_train_s, rounds, world, W, H, n_views=8):
+    """Whole-job numbers of the eight-view loop from every rank's wall time over `rounds` rounds (a round = every rank
+    renders its 8 / N views once): the job is as slow as its slowest rank."""
+    fwd, train = max(per_rank_fwd_s), max(per_rank_train_s)
+    per_rank_views = [len(c5_views_of_rank(r, world, n_views)) for r in range(world)]
+    return {"views": n_views, "views_per_rank": per_rank_views, "rounds": rounds,
+            "fwd_ms_per_round": round(fwd / rounds * 1e3, 3), "train_ms_per_round": round(train / rounds * 1e3, 3),
+            "fwd_mpixels_per_s": round(n_views * W * H * rounds / fwd / 1e6, 2),
+            "train_mpixels_per_s": round(n_views * W * H * rounds / train / 1e6, 2),
+            "per_rank_fwd_ms_per_view": [round(t / rounds / max(v, 1) * 1e3, 3) for t, v in zip(per_rank_fwd_s, per_rank_views)],
+            "per_rank_train_ms_per_view": [round(t / rounds / max(v, 1) * 1e3, 3) for t, v in zip(per_rank_train_s, per_rank_views)]}
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -184,6 +237,9 @@ def main():
                     help="take the densification statistics in preprocess_bwd's epilogue instead of the stand-alone kernel")
     ap.add_argument("--no-prewarm", action="store_true",
                     help="skip the extra untimed steps in front of each headline region (GPU clock ramp)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the two headline regions + the stage-timer pass (what the rocprofv3 passes run: every launch "
+                         "of a kernel then belongs to the headline view)")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
     # stdout carries exactly one line, the JSON result: native libraries (the RCCL / gloo banners) write to fd 1 too,
@@ -271,23 +327,31 @@ def main():
                 dist.barrier(device_ids=[dev.index])
         torch.cuda.synchronize(dev)
 
-    def fwd_step():
+    def fwd_step(c=None):
         with torch.no_grad():
-            return render(cam, model, pipe, bg)
+            return render(c or cam, model, pipe, bg)
 
     loss_vec = torch.zeros(4, device=dev)
+    from mvs_gaussian_splatting_amd import l1_dssim_loss
 
-    def train_step():
+    def train_step(c=None, tgt=None, dssim=False):
         for p in model.parameters():
             p.grad = None
-        pkg = render(cam, model, pipe, bg)
-        loss = l1_loss(pkg["render"], target)
+        pkg = render(c or cam, model, pipe, bg)
+        img, gt = pkg["render"], (target if tgt is None else tgt)
+        loss = l1_dssim_loss(img, gt, 0.2) if dssim else l1_loss(img, gt)     # train.py:99-101 (lambda_dssim = 0.2) / C4's L1
         loss.backward()
         add_densification_stats(model, pkg["viewspace_points"], pkg["radii"])
         if world > 1:     # the path's only collective: [loss_sum, l1_sum, n_views, pad]
             loss_vec[0] = loss.detach(); loss_vec[1] = loss.detach(); loss_vec[2] = 1.0
             all_reduce(loss_vec, dist.ReduceOp.SUM)
         return pkg, loss
+
+    # the eight C5 orbit views partitioned {r, r + N, ...}
+    from mvs_gaussian_splatting_amd.synthetic import orbit_camera
+    my_views = c5_views_of_rank(rank, world)
+    c5_cams = [orbit_camera(v, 8, W, H, cfg.fx, cfg.fy, device=dev) for v in my_views]
+    c5_targets = [torch.rand(3, H, W, generator=torch.Generator().manual_seed(1 + v)).to(dev) for v in my_views]
 
     for _ in range(args.warmup):
         fwd_step()
@@ -348,15 +412,30 @@ def main():
     # The W warm-up steps above take ~10 ms in all: not long enough for the GPU to leave its idle clocks (per-frame time
     # falls from 1.03 to 0.91 ms over the first ~30 frames of a cold region, profiles/r03/clock_ramp.txt; the host issues
     # a frame in 0.13 ms and is never what the GPU waits for).  A sustained run is what the metric describes, so each
-    # headline region is preceded by a fixed number of further UNTIMED steps of its own kind; they are reported in the line.
+    # headline region is preceded by a fixed number of further UNTIMED steps of its own kind; they are reported in the
+    # line, and the first K of them are timed as the COLD region and reported beside the headline.
     prewarm = {"fwd": 0 if args.no_prewarm else 60, "train": 0 if args.no_prewarm else 25}
-    for _ in range(prewarm["fwd"]):
-        fwd_step()
+    cold = {}
+    if not args.no_prewarm:
+        t_c, _ = timed(fwd_step, K)
+        cold["cold_fwd_ms"] = round(t_c / K * 1e3, 3)
+        for _ in range(max(0, prewarm["fwd"] - K)):
+            fwd_step()
     # Headline regions: EXACTLY K steps each, nothing but the steps between the barriers.
     t_fwd, (fwd_steps, fwd_order) = timed(fwd_step, K)
-    for _ in range(prewarm["train"]):
-        train_step()
+    if not args.no_prewarm:
+        t_c, _ = timed(train_step, K)
+        cold["cold_train_ms"] = round(t_c / K * 1e3, 3)
+        for _ in range(max(0, prewarm["train"] - K)):
+            train_step()
     t_train, (train_steps, train_order) = timed(train_step, K)
+    # every rank's own device time of the two headline regions (sum of its per-step event intervals), gathered
+    per_rank = torch.zeros(2 * world, dtype=torch.float64, device=dev)
+    per_rank[2 * rank] = sum(fwd_order) / K
+    per_rank[2 * rank + 1] = sum(train_order) / K
+    if world > 1:
+        all_reduce(per_rank, dist.ReduceOp.SUM)
+    per_rank = per_rank.cpu().tolist()
     # Per-kernel times for the roofline objects: the same K + K steps once more with the library's stage timers on (a HIP
     # event pair around every stage, on the stream the kernels run on).  Kept out of the headline regions because the
     # 14-16 event records per frame cost the frame 5-10 % (they serialise the stream: `profiled_*_ms` below shows it).
@@ -367,14 +446,51 @@ def main():
         t_train_prof, _ = timed(train_step, K)
         stages_train = prof.collect()
     prof.close()
+    # the reference's real training loss (train.py:99-101): same step, fused L1 + D-SSIM kernel pair instead of L1
+    extras = not args.headline_only
+    t_dssim = float("nan")
+    if extras:
+        for _ in range(3):
+            train_step(dssim=True)
+        t_dssim, _ = timed(lambda: train_step(dssim=True), K)
+    # upstream's host synchronisation: the count read back in every frame (GSR_SYNC_FREE=0)
+    from mvs_gaussian_splatting_amd import rasterizer as _rz
+    sync_mode = _rz.sync_free_mode()
+    _rz.synchronize_counts()
+    readback = {}
+    if extras and sync_mode != _rz.SYNC_OFF:
+        _rz.set_sync_free(False)
+        for _ in range(3):
+            fwd_step(); train_step()
+        t_rb_f, _ = timed(fwd_step, K)
+        t_rb_t, _ = timed(train_step, K)
+        readback = {"fwd_ms_readback_every_frame": round(t_rb_f / K * 1e3, 3),
+                    "train_ms_readback_every_frame": round(t_rb_t / K * 1e3, 3)}
+        _rz.set_sync_free(sync_mode)
+    # SURVEY §8e's partition of the EIGHT views: a round = every rank renders its 8 / N views once (at N = 1 the rotating
+    # camera: R changes from frame to frame, so the capacity-based forward runs under a varying instance count)
+    rounds = max(2, K // 4)
+
+    def c5_fwd_round():
+        for c in c5_cams:
+            fwd_step(c)
+
+    def c5_train_round():
+        for c, tg in zip(c5_cams, c5_targets):
+            train_step(c, tg)
+
+    c5 = None
+    if extras:
+        c5_fwd_round(); c5_train_round()
+        t_c5_f, _ = timed(c5_fwd_round, rounds)
+        t_c5_t, _ = timed(c5_train_round, rounds)
+        c5 = c5_summary([t_c5_f] * world, [t_c5_t] * world, rounds, world, W, H)     # timed() already took the MAX over ranks
+        c5["reissued_frames"] = _rz.reissued_frames(dev, P, W, H)
     # The literal drop-in (INTEGRATION.md option A: the reference's own render() feeding the operator through the
     # getters of scene/gaussian_model.py:151-183 -- torch cat / exp / normalize / sigmoid and their autograd) next to
     # the fused raw-parameter path the headline numbers use; a shorter timed region of the same protocol.
-    from mvs_gaussian_splatting_amd import rasterizer as _rz
-    sync_free = _rz._sync_free_value
-    _rz.synchronize_counts()
     unfused = None
-    if pipe.fuse_activations and world == 1:
+    if extras and pipe.fuse_activations and world == 1:
         pipe.fuse_activations = False
         fuse_stats_was, pipe.fuse_densify_stats = pipe.fuse_densify_stats, False
         k2 = max(3, K // 4)
@@ -387,40 +503,9 @@ def main():
         pipe.fuse_activations = True
         pipe.fuse_densify_stats = fuse_stats_was
 
-    # Not part of `value`: the forward of a FIXED model with three frames in flight on three streams (MultiStreamRenderer:
-    # the reference's render.py situation, a trained model and a list of cameras).  A frame is HBM-bound for two thirds
-    # and VALU-bound for the last, so frames on different streams overlap the two.
-    multi = None
-    if world == 1:
-        try:
-            from mvs_gaussian_splatting_amd.graphed import MultiStreamRenderer
-            with torch.no_grad():
-                mr = MultiStreamRenderer(model, pipe, bg, streams=3)
-                views = [cam] * 48
-                for _ in mr.render_views(views[:12]):
-                    pass
-                mr.check()
-                dts = []
-                for _rep in range(3):
-                    torch.cuda.synchronize(dev)
-                    t0 = time.perf_counter()
-                    for _ in mr.render_views(views):
-                        pass
-                    mr.check()
-                    dts.append((time.perf_counter() - t0) / len(views))
-                dt = min(dts)
-                print(f"[bench] multi-stream forward, 3 x {len(views)} frames: " + ", ".join(f"{x * 1e3:.3f}" for x in dts) +
-                      " ms per frame", file=sys.stderr, flush=True)
-                del mr
-            multi = {"streams": 3, "frames": len(views), "ms_per_frame": round(dt * 1e3, 3),
-                     "mpixels_per_s": round(W * H / dt / 1e6, 1),
-                     "note": "fixed model, forward only, frames of the same view in flight on three streams; images "
-                             "bit-identical to render() (tests/test_gpu_graphed.py); NOT the headline value"}
-        except Exception as ex:  # noqa: BLE001
-            multi = {"streams": 3, "ms_per_frame": None, "note": f"failed: {ex!r}"}
-
     # instances of this rank's view: read back from the stage the operator itself ran
     from mvs_gaussian_splatting_amd.rasterizer import frame_counts
+    pkg, _ = train_step()
     R = int(frame_counts(pkg["render"])[0]) if pkg["render"].grad_fn is not None else 0
 
     if rank == 0:
@@ -476,6 +561,10 @@ def main():
             tj = json.load(open(tfile))
         except Exception:  # noqa: BLE001
             tj = {}
+        try:
+            static_mix = json.load(open(os.path.join(ROOT, "profiles", "valu_static_mix.json")))
+        except Exception:  # noqa: BLE001
+            static_mix = {}
         stamp = tj.get("_stamp", {}).get(args.config, {})
         abi_now = _lib.load().gsr_abi_version()
         stamp_ok = bool(stamp) and stamp.get("source_sha16") == source_stamp() and stamp.get("abi") == abi_now
@@ -513,9 +602,21 @@ def main():
                          "note": "utilisations are lower bounds of a unit's busy share at the 2.4 GHz peak clock (the chip "
                                  "clocks at 1.9-2.3 GHz under VALU load; half- and quarter-rate instructions occupy the "
                                  "VALU for 2-3.5x the floor) and cannot exceed 1"}
-            out = {"kernel": kernel, "bound": "hbm", "achieved": table[kernel]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                   "unit": "GB/s", "frac": table[kernel]["frac_of_hbm_peak"], "traffic": entry.get("hbm_bytes_per_launch"),
+            # Which roof binds: the HBM fraction (algorithmic bytes / time / 8 TB/s) against the instruction-issue fraction
+            # (VALU instructions of one --pmc pass priced at their measured issue rates, over the SIMD cycles of the
+            # launch at the clock the GRBM counter of another pass gives for this kernel).  Both are in the object; `bound`
+            # names the larger one, `frac` stays the HBM fraction north_star asks for.
+            im = None
+            mix = entry.get("valu_mix")
+            if mix:
+                rest_cost = static_mix.get(kernel, {}).get("rest_cost_cycles", 4.5)
+                im = issue_model(mix, rest_cost, t_s, float(entry.get("clock_GHz_pmc") or 2.4) * 1e9)
+            hbm_frac = table[kernel]["frac_of_hbm_peak"]
+            bound = "valu_issue" if (im and im["frac_of_issue_roof"] > hbm_frac) else "hbm"
+            out = {"kernel": kernel, "bound": bound, "achieved": table[kernel]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                   "unit": "GB/s", "frac": hbm_frac, "traffic": entry.get("hbm_bytes_per_launch"),
                    "avg_launch_ms": table[kernel]["avg_ms"], "algorithmic_bytes_per_launch": alg[kernel],
+                   "frac_of_issue_roof": im["frac_of_issue_roof"] if im else None, "issue_model": im,
                    "issue": issue, "pmc_source": pmc_note}
             if kernel in moved:
                 out.update({"byte_model": table[kernel]["byte_model"],
@@ -539,10 +640,15 @@ def main():
             "value": round(world * W * H / (t_fwd / K) / 1e6, 2), "unit": "Mpixels/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup,
             "extra_untimed_warmup_steps": dict(prewarm, why="GPU clock ramp after idle: see profiles/r03/clock_ramp.txt; "
-                                                            "--no-prewarm measures the cold region"),
+                                                            "the first K of them are the cold_* region; --no-prewarm makes "
+                                                            "the cold region the headline"),
             "ms_per_step": round(train_ms, 3), "fwd_ms_per_step": round(fwd_ms, 3),
             "train_mpixels_per_s": round(world * W * H / (t_train / K) / 1e6, 2),
             "fwd_fps": round(1e3 / fwd_ms, 2),
+            "train_step_ms_l1_dssim": round(t_dssim / K * 1e3, 3) if extras else None,
+            "per_rank_fwd_ms": [round(per_rank[2 * r], 4) for r in range(world)],
+            "per_rank_train_ms": [round(per_rank[2 * r + 1], 4) for r in range(world)],
+            "c5_eight_views": c5,
             "profiled_fwd_ms": round(t_fwd_prof / K * 1e3, 3), "profiled_train_ms": round(t_train_prof / K * 1e3, 3),
             "fwd_step_ms_in_order": [round(v, 3) for v in fwd_order], "train_step_ms_in_order": [round(v, 3) for v in train_order],
             "fwd_step_ms_p10_p50_p90": [pct(fwd_steps, 0.1), pct(fwd_steps, 0.5), pct(fwd_steps, 0.9)],
@@ -550,14 +656,18 @@ def main():
             "hbm_copy_measured_GBs": copy_GBs,
             "hbm_elementwise_kernel_GBs": round(getattr(copy_ceiling, "kernel_rate", 0.0), 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {P} Gaussians, SH degree {cfg.sh_degree}, {W}x{H}, one view per GPU; "
-                                   "value = forward-only steps, ms_per_step = render+L1+backward+densify-stats steps",
+            "config": {"workload": f"{args.config}: {P} Gaussians, SH degree {cfg.sh_degree}, {W}x{H}, one view per GPU "
+                                   f"(rank r renders orbit view r of 8); value = forward-only steps, ms_per_step = "
+                                   "render+L1+backward+densify-stats steps",
                        "gaussians": P, "visible": visible, "instances_R": R, "views_per_step": world,
                        "inputs": ("raw parameters (split SH, exp/normalize/sigmoid inside the kernels; INTEGRATION.md "
                                   "option B -- the literal drop-in through the reference getters is unfused_*_ms)"
                                   if pipe.fuse_activations else "reference getters (torch cat/exp/normalize/sigmoid)"),
-                       "host_sync": ("first frame reads num_rendered back, later frames run gsr_forward with a capacity "
-                                     "(no read-back)" if sync_free else "num_rendered read back in every frame"),
+                       "host_sync": {_rz.SYNC_OFF: "num_rendered read back in every frame",
+                                     _rz.SYNC_VERIFIED: "first frame of a shape reads num_rendered back; later frames are enqueued "
+                                                        "whole with a capacity, the host waits for the scan kernel's event only "
+                                                        "and re-issues a frame that did not fit (never an incomplete image)",
+                                     _rz.SYNC_DEFERRED: "deferred count check (opt-in: an overflowed frame raises later)"}[sync_mode],
                        "densify_stats": "fused into preprocess_bwd" if pipe.fuse_densify_stats else "stand-alone kernel",
                        "collective_backend": backend_note if world > 1 else None,
                        "rccl_ranks": rccl_ranks,
@@ -573,10 +683,10 @@ def main():
             "roofline_by_kernel": table,
             "fwd_algorithmic_GB": round(sum(alg[n] for n in fwd_names) / 1e9, 3),
         }
+        line.update(cold)
+        line.update(readback)
         if unfused:
             line.update(unfused)
-        if multi:
-            line["fwd_multi_stream"] = multi
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(cfg, args.seed)

@@ -110,3 +110,46 @@ def test_byte_models_of_the_roofline_objects():
     assert v2["preprocess_fwd"] == 44 * P + (12 * M + 75) * 3_880_905 < v1["preprocess_fwd"]
     assert bench.bytes_really_moved(P, M, 0, 0, W, H)["preprocess_fwd"] == 44 * P      # nothing visible: 44 B per Gaussian
     assert v2["preprocess_bwd"] < v1["preprocess_bwd"] + 49 * 8_192_108
+
+
+def _bench_module():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_eight_views_are_partitioned_round_robin_and_summarised_from_the_slowest_rank(world):
+    """rank r renders views {r, r + N, ...} of the eight; every view exactly once; the whole-job numbers of the
+    eight-view loop come from the slowest rank, the per-rank fields keep every rank's own time per view."""
+    bench = _bench_module()
+    parts = [bench.c5_views_of_rank(r, world) for r in range(world)]
+    assert sorted(v for p in parts for v in p) == list(range(8))
+    assert all(p == list(range(r, 8, world)) for r, p in enumerate(parts))
+    assert all(len(p) == 8 // world for p in parts)
+    W, H, rounds = 1920, 1080, 5
+    fwd = [0.010 * (1 + 0.1 * r) for r in range(world)]          # seconds over `rounds` rounds, rank r a little slower
+    train = [0.025 * (1 + 0.2 * r) for r in range(world)]
+    s = bench.c5_summary(fwd, train, rounds, world, W, H)
+    assert s["views_per_rank"] == [8 // world] * world and s["views"] == 8 and s["rounds"] == rounds
+    assert s["fwd_ms_per_round"] == round(max(fwd) / rounds * 1e3, 3)
+    assert s["train_ms_per_round"] == round(max(train) / rounds * 1e3, 3)
+    assert s["fwd_mpixels_per_s"] == round(8 * W * H * rounds / max(fwd) / 1e6, 2)
+    assert len(s["per_rank_fwd_ms_per_view"]) == world
+    assert s["per_rank_train_ms_per_view"][0] == round(train[0] / rounds / (8 // world) * 1e3, 3)
+
+
+def test_issue_roof_model_prices_the_counted_classes_at_their_measured_rates():
+    """frac_of_issue_roof = (2.4 full-rate + 8.2 transcendental + rest_cost rest) cycles / (1024 SIMDs x clock x t)."""
+    bench = _bench_module()
+    mix = {"SQ_INSTS_VALU": 1000, "SQ_INSTS_VALU_ADD_F32": 100, "SQ_INSTS_VALU_MUL_F32": 100, "SQ_INSTS_VALU_FMA_F32": 200,
+           "SQ_INSTS_VALU_TRANS_F32": 50, "SQ_INSTS_VALU_INT32": 150, "SQ_INSTS_VALU_INT64": 0, "SQ_INSTS_VALU_CVT": 0}
+    m = bench.issue_model(mix, 4.0, 1e-6, 2.0e9)
+    cycles = 2.4 * 550 + 8.2 * 50 + 4.0 * 400
+    assert m["full_rate"] == 550 and m["transcendental"] == 50 and m["rest"] == 400
+    assert m["valu_issue_cycles"] == int(cycles)
+    assert m["frac_of_issue_roof"] == round(cycles / (1024 * 2.0e9 * 1e-6), 4)
+    assert bench.issue_model({}, 4.0, 1e-6, 2.0e9) is None and bench.issue_model(mix, 4.0, 0.0, 2.0e9) is None

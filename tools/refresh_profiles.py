@@ -33,7 +33,8 @@ for f in glob.glob(os.path.join(src, "bench_*.json")):
     shutil.copy(f, os.path.join(dst, os.path.basename(f)))
 ks = one("stats/**/*_kernel_stats.csv")
 shutil.copy(ks, os.path.join(dst, "rocprofv3_kernel_stats_bench_c4.csv"))
-for d, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"), ("sq", "SQ"), ("sq2", "SQ2")):
+for d, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"), ("sq", "SQ"), ("sq2", "SQ2"), ("sq3", "SQ3_valu_mix"),
+                ("grbm", "GRBM_clock")):
     try:
         shutil.copy(one(f"{d}/**/*_counter_collection.csv"), os.path.join(dst, f"pmc_{name}_bench_c4_counter_collection.csv"))
     except IndexError:
@@ -87,6 +88,38 @@ for stage, sq in best.items():
     e.pop("valu_insts_per_launch", None); e.pop("valu_method", None)
     e["sq"] = {c: int(v) for c, v in sq.items()}
     e["sq_method"] = "rocprofv3 --pmc SQ_* (two separate passes), per-launch mean, wave-level instruction counts"
+# VALU instruction classes (one pass) and the clock every kernel ran at (GRBM_GUI_ACTIVE is summed over the 8 XCDs: cycles
+# = value / 8; duration = the dispatch's own timestamps in that pass) -> the issue-roof model of bench.py
+mix = collections.defaultdict(lambda: collections.defaultdict(list))
+p3 = os.path.join(dst, "pmc_SQ3_valu_mix_bench_c4_counter_collection.csv")
+if os.path.exists(p3):
+    for r in csv.DictReader(open(p3)):
+        base = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].split("::")[-1]
+        if base in names:
+            mix[names[base]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+clk = collections.defaultdict(list)
+pg = os.path.join(dst, "pmc_GRBM_clock_bench_c4_counter_collection.csv")
+if os.path.exists(pg):
+    for r in csv.DictReader(open(pg)):
+        base = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].split("::")[-1]
+        dt = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+        if base in names and r["Counter_Name"] == "GRBM_GUI_ACTIVE" and dt > 0:
+            clk[names[base]].append(float(r["Counter_Value"]) / 8.0 / dt)      # cycles per ns = GHz
+with open(os.path.join(dst, "pmc_valu_mix_summary.txt"), "w") as f:
+    f.write("# rocprofv3 --pmc SQ_INSTS_VALU + its ADD/MUL/FMA/TRANS/INT32/INT64/CVT sub-counters (one pass) and --pmc "
+            "GRBM_GUI_ACTIVE (its own pass) -- python bench.py --headline-only; per-launch means of the wave-level counts; "
+            "clock = GRBM_GUI_ACTIVE / 8 XCDs / dispatch duration (median over the launches; reads high on dispatches "
+            "shorter than ~0.3 ms per the guide)\n")
+    for stage in names.values():
+        e = tj["C4"].setdefault(stage, {})
+        if stage in mix:
+            # a kernel with two template instances (render_fwd tracking / forward-only): the launches are pooled
+            e["valu_mix"] = {c: int(sum(v) / len(v)) for c, v in mix[stage].items()}
+        if stage in clk:
+            v = sorted(clk[stage])
+            e["clock_GHz_pmc"] = round(v[len(v) // 2], 3)
+        if stage in mix or stage in clk:
+            f.write(f"{stage}: clock {e.get('clock_GHz_pmc')} GHz; " + ", ".join(f"{c}={n}" for c, n in sorted(e.get("valu_mix", {}).items())) + "\n")
 lib_abi = int([l for l in open(os.path.join(os.path.dirname(here), "include", "gsr.h")) if "define GSR_ABI_VERSION" in l][0].split()[-1])
 tj.setdefault("_stamp", {})["C4"] = {"source_sha16": bench.source_stamp(), "abi": lib_abi, "label": label}
 json.dump(tj, open(tpath, "w"), indent=1)
