@@ -19,8 +19,9 @@ printed for every tensor.  (Worst bars seen on the round-2 suite: means2D 2.9e-5
 
 The masked pixels are not left unchecked: compare_grads_unmasked() runs the same scene with EVERY pixel in the loss
 (plain L1) against float64 and requires finite gradients within 2e-3 (max-norm relative) when the scene has no
-threshold-fragile pixel, 2e-2 when it has: a float32 and a float64 evaluation may take different decisions on such a
-pixel, and each flip moves a gradient by the pixel's whole contribution (a soak over fuzz seeds 72..179 saw up to
+threshold-fragile pixel, and within 2e-3 + 2 x (the share of the float64 gradient that the fragile pixels carry, per
+tensor) when it has -- at most 2e-2: a float32 and a float64 evaluation may take different decisions on such a
+pixel, and each flip moves a gradient by about the pixel's contribution (a soak over fuzz seeds 72..179 saw up to
 6.3e-3 with 19 fragile pixels in the loss, 3.9e-3 with two; the masked comparison of the same scenes stayed at the
 float32 oracle's own error).  What that run cannot tell apart from such a flip -- the backward taking a different
 decision than the FORWARD on a threshold pixel (clamp scope, list cut-off, last contributor) -- is checked exactly and
@@ -117,11 +118,17 @@ def compare_grads(got, ref, ref32=None, label=""):
     return rows
 
 
-def compare_grads_unmasked(got, ref, n_fragile, label=""):
-    """Every pixel in the loss (weights all one): finite, and within UNMASKED_TOL (UNMASKED_TOL_FRAGILE when
-    threshold-fragile pixels carry weight) of float64 per tensor, max-norm relative."""
+def compare_grads_unmasked(got, ref, n_fragile, label="", ref_masked=None):
+    """Every pixel in the loss (weights all one): finite, and per tensor (max-norm relative to float64) within
+
+        UNMASKED_TOL                                  when no threshold-fragile pixel carries weight,
+        UNMASKED_TOL + 2 x (fragile share)            when some do, never more than UNMASKED_TOL_FRAGILE,
+
+    where the fragile share of a tensor is max|g64(all pixels) - g64(fragile pixels masked)| / max|g64(all pixels)|: the
+    part of the float64 gradient that comes from the pixels on which a float32 evaluation may decide differently.  A flip
+    moves a gradient by about what the pixel contributes, so a scene whose fragile pixels carry 1e-4 of the gradient is
+    held to 2.2e-3, not to the flat 2e-2 of round 3.  Without ref_masked the flat bar applies."""
     rows, bad = [], {}
-    tol = UNMASKED_TOL_FRAGILE if n_fragile > 0 else UNMASKED_TOL
     for k, r in ref.items():
         if r.numel() == 0:
             continue
@@ -131,9 +138,16 @@ def compare_grads_unmasked(got, ref, n_fragile, label=""):
         scale = float(r.abs().max())
         if scale == 0.0:
             continue
+        if n_fragile <= 0:
+            tol, share = UNMASKED_TOL, 0.0
+        elif ref_masked is None:
+            tol, share = UNMASKED_TOL_FRAGILE, float("nan")
+        else:
+            share = float((r - ref_masked[k].double()).abs().max()) / scale
+            tol = min(UNMASKED_TOL_FRAGILE, UNMASKED_TOL + 2.0 * share)
         e = float((g - r).abs().max()) / scale
-        rows.append(f"{k}: {e:.2e}")
+        rows.append(f"{k}: {e:.2e} (fragile share {share:.1e}, bar {tol:.1e})")
         if e > tol:
-            bad[k] = e
+            bad[k] = (e, tol)
     print(f"[grad parity, unmasked, {n_fragile} fragile pixels in the loss] {label}: " + "; ".join(rows))
-    assert not bad, f"{label}: unmasked gradient error above {tol}: {bad}"
+    assert not bad, f"{label}: unmasked gradient error above the per-scene bar: {bad}"

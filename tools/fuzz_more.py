@@ -32,4 +32,8 @@ for seed in range(lo, hi):
         traceback.print_exc()
 print("skipped (ill-conditioned):", skipped)
 print("failed seeds:", bad)
+n = max(hi - lo, 1)
+if len(skipped) > max(2, n // 20):
+    print(f"too many scenes refused as ill-conditioned ({len(skipped)} of {n}): the soak proves less than it claims")
+    sys.exit(2)
 sys.exit(1 if bad else 0)
