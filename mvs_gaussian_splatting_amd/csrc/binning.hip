@@ -172,13 +172,19 @@ __global__ __launch_bounds__(PRE_BLOCK) void count_tiles_kernel(const uint32_t* 
 // takes output slots (not Gaussians), finds the owning Gaussian by binary search in the block's inclusive scan
 // (LDS) and derives the tile from the slot's rank inside the rect -- fully coalesced stores, no divergence on
 // the splat size (a per-Gaussian loop here ran at 0.5 TB/s).
-__global__ __launch_bounds__(PRE_BLOCK) void emit_instances_kernel(const uint32_t* __restrict__ total, int grid_x,
+// THREADS: 256, or 1024 for small frames (a 100 k-Gaussian frame has ~100 blocks of ~2000 instances: with 256 threads each
+// block walks its run in eight trips while most of the chip idles); the first 256 threads load and scan, all emit.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void emit_instances_kernel(const uint32_t* __restrict__ total, int grid_x,
                                                                    const uint2* __restrict__ d3,
                                                                    const uint2* __restrict__ d4,
                                                                    const BinInfo* __restrict__ bin,
                                                                    const uint32_t* __restrict__ block_offs2,
                                                                    uint32_t* __restrict__ inst_tile,
                                                                    uint32_t* __restrict__ inst_g, uint32_t capacity) {
+  // THREADS == 1024 (small frames, at most EMIT_WIDE_MAX_BLOCKS blocks): block_offs2 holds the block TOTALS of
+  // count_tiles, not their scan -- every block sums the totals in front of it itself (one load per thread) and the scan
+  // kernel between the two is not launched
   const uint32_t V = total[TOTAL_V];
   if (blockIdx.x * PRE_BLOCK >= V) return;      // grid sized for a capacity (uniform exit: no barrier crossed)
   const uint2* __restrict__ dval = total[TOTAL_TOP_PASS_N] ? d4 : d3;
@@ -189,10 +195,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void emit_instances_kernel(const uint32_
   __shared__ uint32_t s_wh[PRE_BLOCK];        // rect width | height << 16
   __shared__ uint32_t s_mask[PRE_BLOCK];      // tile mask (BinInfo::mask)
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+  const bool loader = THREADS == PRE_BLOCK || tid < PRE_BLOCK;
   const uint32_t i = blockIdx.x * PRE_BLOCK + tid;
   uint32_t g = 0, tiles = 0, mask = 0;
   uint2 rr = make_uint2(0u, 0u);
-  if (i < V) {
+  if (loader && i < V) {
     const uint2 v = dval[i];
     g = v.x;
     if (v.y & PACK_FALLBACK) {
@@ -205,21 +212,35 @@ __global__ __launch_bounds__(PRE_BLOCK) void emit_instances_kernel(const uint32_
     tiles = bin_count(rr.y, mask);
   }
   const uint32_t inc = wave_incl_scan_u32(tiles);
-  if (lane == WAVE - 1) wave_tot[wid] = inc;
+  if (loader && lane == WAVE - 1) wave_tot[wid] = inc;
   __syncthreads();
-  uint32_t wbase = 0;
+  if (loader) {
+    uint32_t wbase = 0;
 #pragma unroll
-  for (int w = 0; w < PRE_BLOCK / WAVE; ++w)
-    if (w < wid) wbase += wave_tot[w];
-  s_incl[tid] = wbase + inc;
-  s_g[tid] = g;
-  s_min[tid] = rr.x;
-  s_wh[tid] = rr.y;
-  s_mask[tid] = mask;
+    for (int w = 0; w < PRE_BLOCK / WAVE; ++w)
+      if (w < wid) wbase += wave_tot[w];
+    s_incl[tid] = wbase + inc;
+    s_g[tid] = g;
+    s_min[tid] = rr.x;
+    s_wh[tid] = rr.y;
+    s_mask[tid] = mask;
+  }
   __syncthreads();
   const uint32_t n_out = s_incl[PRE_BLOCK - 1];
-  const uint32_t base = block_offs2[blockIdx.x];
-  for (uint32_t o = (uint32_t)tid; o < n_out; o += PRE_BLOCK) {
+  uint32_t base;
+  if (THREADS == PRE_BLOCK) {
+    base = block_offs2[blockIdx.x];
+  } else {
+    __shared__ uint32_t s_part[THREADS / WAVE];
+    const uint32_t mine = (uint32_t)tid < blockIdx.x ? block_offs2[tid] : 0u;       // blockIdx.x < EMIT_WIDE_MAX_BLOCKS <= THREADS
+    const uint32_t ws = wave_reduce_add_u32(mine);
+    if (lane == 0) s_part[wid] = ws;
+    __syncthreads();
+    base = 0;
+#pragma unroll
+    for (int w = 0; w < THREADS / WAVE; ++w) base += s_part[w];
+  }
+  for (uint32_t o = (uint32_t)tid; o < n_out; o += THREADS) {
     // smallest j with s_incl[j] > o
     int lo = 0, hi = PRE_BLOCK - 1;
 #pragma unroll
@@ -970,9 +991,13 @@ void launch_emit_instances(uint32_t v_cap, const uint32_t* total, int grid_x, co
                            const BinInfo* bin, const uint32_t* block_offs2, uint32_t* inst_tile, uint32_t* inst_g,
                            uint32_t capacity, hipStream_t s) {
   const uint32_t nb = (v_cap + PRE_BLOCK - 1) / PRE_BLOCK;
-  if (nb)
-    hipLaunchKernelGGL(emit_instances_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, total, grid_x, d3, d4, bin, block_offs2,
+  if (nb == 0) return;
+  if (emit_is_wide(v_cap))      // fewer blocks than two per CU: four times the threads per block for the emission loop
+    hipLaunchKernelGGL(emit_instances_kernel<1024>, dim3(nb), dim3(1024), 0, s, total, grid_x, d3, d4, bin, block_offs2,
                        inst_tile, inst_g, capacity);
+  else
+    hipLaunchKernelGGL(emit_instances_kernel<PRE_BLOCK>, dim3(nb), dim3(PRE_BLOCK), 0, s, total, grid_x, d3, d4, bin,
+                       block_offs2, inst_tile, inst_g, capacity);
 }
 void launch_reconstruct_keys(uint32_t R, uint32_t P, const uint32_t* tile_sorted, const uint32_t* point_list,
                              const BinInfo* bin, uint64_t* keys, hipStream_t s) {

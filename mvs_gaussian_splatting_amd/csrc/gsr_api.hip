@@ -324,8 +324,12 @@ static int enqueue_stage2(const GsrParams* p, void* geom_ws, void* bin_ws, size_
       {
         StageTimer t(p, GSR_STAGE_DUPLICATE, s);   // instances emitted in depth order
         launch_count_tiles(v_cap, total, d3, d4, bin, bsum2, s);
-        launch_scan_block_sums(bsum2, boffs2, boffs2 + B.nblocks2 + 1, nullptr, nullptr, nullptr, (int)B.nblocks2, s);
-        launch_emit_instances(v_cap, total, I.grid_x, d3, d4, bin, boffs2, ita, iga, cap, s);
+        if (emit_is_wide(v_cap)) {      // small frame: the emission sums the block totals itself, no scan launch
+          launch_emit_instances(v_cap, total, I.grid_x, d3, d4, bin, bsum2, ita, iga, cap, s);
+        } else {
+          launch_scan_block_sums(bsum2, boffs2, boffs2 + B.nblocks2 + 1, nullptr, nullptr, nullptr, (int)B.nblocks2, s);
+          launch_emit_instances(v_cap, total, I.grid_x, d3, d4, bin, boffs2, ita, iga, cap, s);
+        }
       }
       if (int rc = check(p, s, "emit_instances")) return rc;
       const uint32_t* r_dev = device_counts ? total + TOTAL_R_CLAMPED : nullptr;

@@ -67,6 +67,11 @@ void launch_sort_extra_pass_u32(const uint32_t* kin, const uint2* vin, uint32_t*
 // d3 / d4: the depth-sorted payload after the three regular passes / after the top-digit pass (chosen on the device)
 void launch_count_tiles(uint32_t v_cap, const uint32_t* total, const uint2* d3, const uint2* d4, const BinInfo* bin,
                         uint32_t* block_sums2, hipStream_t s);
+// Small frames (at most EMIT_WIDE_MAX_BLOCKS blocks of 256 depth-sorted Gaussians): emit_instances runs with 1024 threads
+// per block and takes the block TOTALS of count_tiles as block_offs2 (it sums the totals in front of each block itself):
+// the caller then skips the scan between the two kernels.
+constexpr uint32_t EMIT_WIDE_MAX_BLOCKS = 512;
+inline bool emit_is_wide(uint32_t v_cap) { return (v_cap + PRE_BLOCK - 1) / PRE_BLOCK <= EMIT_WIDE_MAX_BLOCKS; }
 void launch_emit_instances(uint32_t v_cap, const uint32_t* total, int grid_x, const uint2* d3, const uint2* d4,
                            const BinInfo* bin, const uint32_t* block_offs2, uint32_t* inst_tile, uint32_t* inst_g,
                            uint32_t capacity, hipStream_t s);
