@@ -579,14 +579,84 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(GsrParams p, 
   GeomRec r;
   float dcxx = 0.f, dcxy = 0.f, dcyy = 0.f;
   bool any_row = false;
+  uint32_t n_rows = 0, slot0 = 0;
   if (vis) {
     r = rec[idx];
     const uint32_t n_all = bin_count(r.rect_wh, r.tile_mask);
-    const uint32_t n_rows = n_all > ROWS_COOP ? 1u : n_all;
-    const uint32_t slot0 = slot_base[idx];
+    n_rows = n_all > ROWS_COOP ? 1u : n_all;
+    slot0 = slot_base[idx];
+  }
+#ifndef GSR_BWD_ROWS_PER_LANE
+  // The wave reads the rows of its 64 Gaussians TOGETHER: the rows are numbered 0 .. T-1 across the wave (prefix sum of the
+  // row counts), 256 of them per trip -- every lane requests the flag bytes of four rows, then the flagged rows, whoever
+  // owns them -- and are laid out in LDS in that order; each lane then adds ITS rows from LDS in slot order.  The order of
+  // the additions is the same as before (bitwise reproducible, independent of what else shares the wave), but a Gaussian
+  // with 60 rows no longer holds its wave for thirty dependent trips to memory while the other 63 lanes wait: on a
+  // heavy-tailed scene (5.7 rows per Gaussian, up to ROWS_COOP) that was most of this kernel.  The staging area is the
+  // wave's SH output stage, which is not in use yet.
+  {
+    constexpr int RSTRIDE = 10;                                   // nine sums + the flag
+    constexpr uint32_t TRIP = 256;
+    float* stage = sh_stage[wid];                                 // 64 * 49 floats: 256 rows * 10 + two 64-entry tables fit
+    uint32_t* t_excl = reinterpret_cast<uint32_t*>(stage + TRIP * RSTRIDE);
+    uint32_t* t_slot = t_excl + WAVE;
+    static_assert(TRIP * RSTRIDE + 2 * WAVE <= WAVE * SH_ROW, "row staging must fit the SH stage");
+    const uint32_t inc = wave_incl_scan_u32(n_rows), excl = inc - n_rows;
+    const uint32_t T = (uint32_t)__shfl((int)inc, WAVE - 1, WAVE);
+    t_excl[lane] = excl;
+    t_slot[lane] = slot0;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t base = 0; base < T; base += TRIP) {
+      uint32_t slot[4];
+      uint8_t f[4];
+      GradRow q[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t j = base + u * WAVE + (uint32_t)lane;
+        f[u] = 0;
+        slot[u] = 0;
+        if (j < T) {
+          // owner: the last lane whose exclusive prefix is <= j (lanes without rows share their successor's prefix and
+          // come before it)
+          int lo = 0, hi = WAVE - 1;
+#pragma unroll
+          for (int it = 0; it < 6; ++it) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (t_excl[mid] <= j) lo = mid; else hi = mid - 1;
+          }
+          slot[u] = t_slot[lo] + (j - t_excl[lo]);
+          f[u] = row_flags[slot[u]];
+        }
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u)
+        if (f[u]) q[u] = rows[slot[u]];
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) {
+        float* d = stage + (u * WAVE + (uint32_t)lane) * RSTRIDE;
+        if (f[u]) {
+          d[0] = q[u].dmx; d[1] = q[u].dmy; d[2] = q[u].dcxx; d[3] = q[u].dcxy; d[4] = q[u].dcyy;
+          d[5] = q[u].dop; d[6] = q[u].dr; d[7] = q[u].dg; d[8] = q[u].db;
+        }
+        d[9] = f[u] ? 1.0f : 0.0f;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t lo_j = max(excl, base), hi_j = min(excl + n_rows, base + TRIP);
+      for (uint32_t j = lo_j; j < hi_j; ++j) {
+        const float* d = stage + (j - base) * RSTRIDE;
+        if (d[9] != 0.0f) {
+          any_row = true;
+          dm2x += d[0]; dm2y += d[1]; dcxx += d[2]; dcxy += d[3]; dcyy += d[4];
+          dop += d[5]; dcol[0] += d[6]; dcol[1] += d[7]; dcol[2] += d[8];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+#else
+  if (vis) {
     // ROW_BATCH rows per trip to memory: the flag bytes of a batch are requested together, then the flagged rows -- the
-    // additions stay in slot order (bitwise reproducible).  One row per iteration made every row two dependent
-    // round-trips; a heavy-tailed scene (5-6 rows per Gaussian, up to ROWS_COOP) spent most of this kernel there.
+    // additions stay in slot order (bitwise reproducible).
     constexpr uint32_t ROW_BATCH = 4;
     for (uint32_t k = 0; k < n_rows; k += ROW_BATCH) {
       uint8_t f[ROW_BATCH];
@@ -605,6 +675,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(GsrParams p, 
         }
     }
   }
+#endif
 
   // A visible Gaussian that received no row (behind saturated pixels, or below 1/255 everywhere) has every sum zero and
   // therefore every gradient zero: it takes the path of an invisible one -- zeros are written, and its position /
