@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 11
+#define GSR_ABI_VERSION 12
 
 enum {
   GSR_OK = 0,
@@ -79,6 +79,9 @@ typedef struct GsrParams {
                                   last contributor and the per-pixel / per-Gaussian state the backward reads (final
                                   transmittance, contributor counts, gradient-row slots) is not written.  Same image. */
   int32_t debug_flags;         /* GSR_DEBUG_* bits: switches the tests use (never read from the environment) */
+  uint8_t* visible_out;        /* NULL, or device [P] (ABI v12): the forward also stores radii[i] > 0 there -- the
+                                  `visibility_filter = radii > 0` of the reference's render()
+                                  (gaussian_renderer/__init__.py:311) without a pass of its own over the radii */
 } GsrParams;
 
 enum {

@@ -412,6 +412,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
   if (idx < p.P) {
     radii[idx] = radius;
     bin[idx] = bi;
+    if (p.visible_out) p.visible_out[idx] = radius > 0 ? 1 : 0;
   }
 
   // range of the depth keys of the Gaussians that enter the binning: the depth sort works on (bits - min), which

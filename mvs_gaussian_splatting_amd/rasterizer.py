@@ -184,6 +184,7 @@ def _make_params(dev, settings: GaussianRasterizationSettings, means3D, sh, colo
     p.counts_pinned = None
     p.forward_only = int(bool(forward_only))
     p.debug_flags = _debug_flags_value
+    p.visible_out = None
     return p, [bg, view, proj, campos]
 
 
@@ -568,10 +569,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, frame.radii,
                               frame.geom, frame.binning, frame.img)
         ctx.mark_non_differentiable(frame.radii)
+        ctx.set_materialize_grads(False)        # no zeros_like(radii) per backward for the integer output
         return color, frame.radii
 
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii):
+        if grad_out_color is None:
+            return (None,) * 11
         lib = _lib.load()
         (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, geom, binning,
          img) = ctx.saved_tensors
@@ -615,7 +619,8 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations,
-                raster_settings: GaussianRasterizationSettings, forward_only: bool = False, stats=None):
+                raster_settings: GaussianRasterizationSettings, forward_only: bool = False, stats=None, visible=None):
+        """``visible``: None, or a bool [P] tensor the forward fills with ``radii > 0`` (render()'s visibility_filter)."""
         lib = _lib.load()
         dev = _require_gpu(means3D)
         P = int(means3D.shape[0])
@@ -643,6 +648,10 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
             params, keep = _make_params(dev, raster_settings, means3D, f_dc, empty, raw_opacity, raw_scales,
                                         raw_rotations, empty, sh_rest=f_rest if n_rest else None, act_flags=flags,
                                         forward_only=forward_only)
+            if visible is not None:
+                if visible.dtype != torch.bool or visible.numel() != P or not visible.is_contiguous() or visible.device != dev:
+                    raise TypeError("visible must be a contiguous bool [P] tensor on the Gaussians' device")
+                params.visible_out = visible.data_ptr()
             try:
                 color, frame = _run_forward(lib, dev, params, P, W, H)
             except _lib.GsrError:
@@ -663,10 +672,13 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
         ctx.save_for_backward(means3D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations, frame.radii, frame.geom,
                               frame.binning, frame.img)
         ctx.mark_non_differentiable(frame.radii)
+        ctx.set_materialize_grads(False)        # no 24-MB zeros_like(radii) per backward for the integer output
         return color, frame.radii
 
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii):
+        if grad_out_color is None:
+            return (None,) * 11
         lib = _lib.load()
         means3D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations, radii, geom, binning, img = ctx.saved_tensors
         settings = ctx.raster_settings
@@ -696,7 +708,7 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
                     print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise
         del keep
-        return g_means3D, g_means2D, g_dc, g_rest, g_opac, g_scales, g_rot, None, None, None
+        return g_means3D, g_means2D, g_dc, g_rest, g_opac, g_scales, g_rot, None, None, None, None
 
 
 def _forward_only(*tensors) -> bool:
@@ -714,17 +726,21 @@ class _NoGraph:
     def mark_non_differentiable(self, *tensors):
         pass
 
+    def set_materialize_grads(self, value):
+        pass
+
 
 def rasterize_gaussians_fused(means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations, raster_settings,
-                              densify_stats=None):
+                              densify_stats=None, visible=None):
     """``densify_stats``: None, or (xyz_gradient_accum, denom, max_radii2D) -- the backward then also accumulates the
-    densification statistics of ``scene/gaussian_model.py:775-777`` / ``train.py:130``."""
+    densification statistics of ``scene/gaussian_model.py:775-777`` / ``train.py:130``.
+    ``visible``: None, or a bool [P] tensor that receives ``radii > 0`` from the preprocess kernel."""
     if _forward_only(means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations):
         with torch.no_grad():
             return _RasterizeGaussiansFused.forward(_NoGraph(), means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales,
-                                                    raw_rotations, raster_settings, True, None)
+                                                    raw_rotations, raster_settings, True, None, visible)
     return _RasterizeGaussiansFused.apply(means3D, means2D, f_dc, f_rest, raw_opacity, raw_scales, raw_rotations,
-                                          raster_settings, False, densify_stats)
+                                          raster_settings, False, densify_stats, visible)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,

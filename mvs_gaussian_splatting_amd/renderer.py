@@ -96,10 +96,13 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier:
     if _can_fuse(pc, pipe, override_color):
         # same result as the getter path below, without materialising cat(f_dc, f_rest), exp, normalize, sigmoid (and
         # without building an nn.Module per frame: the operator is called as a function)
+        # visibility_filter (= radii > 0, gaussian_renderer/__init__.py:311) is stored by the preprocess kernel itself:
+        # a torch compare over 6 M radii is a 9-us kernel per frame
+        visible = torch.empty(xyz.shape[0], dtype=torch.bool, device=xyz.device)
         rendered_image, radii = rasterize_gaussians_fused(xyz, screenspace_points, pc._features_dc, pc._features_rest,
                                                           pc._opacity, pc._scaling, pc._rotation, raster_settings,
-                                                          densify_stats=stats)
-        return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+                                                          densify_stats=stats, visible=visible)
+        return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": visible,
                 "radii": radii, "selected_pts_mask": None}
 
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
