@@ -201,7 +201,10 @@ def issue_model(valu_mix, rest_cost_cycles, t_s, clock_hz):
     return {"valu_insts": int(total), "full_rate": int(full), "transcendental": int(trans), "rest": int(rest),
             "rest_cost_cycles": rest_cost_cycles, "valu_issue_cycles": int(cycles), "clock_GHz": round(clock_hz / 1e9, 3),
             "frac_of_issue_roof": round(cycles / (SIMDS * clock_hz * t_s), 4),
-            "cycles_per_valu_inst": round(cycles / total, 3)}
+            "cycles_per_valu_inst": round(cycles / total, 3),
+            "uncertainty": "about +-5 %: the class rates are measured in isolation at 8 waves per SIMD, the clock comes from a "
+                           "separate --pmc pass of the same kernel; a value at (or a few per cent above) 1 means the launch "
+                           "left no vector issue slot unused"}
 
 
 def c5_views_of_rank(rank, world, n_views=8):
