@@ -401,10 +401,7 @@ __device__ unsigned long long g_bwd_prof[8];
 constexpr int MB_WIN = 26;                   // list positions a pass can hold
 constexpr int MB_LIST = MB_WIN + 4;          // list row: [0] takes the writes of the lanes that are not in the list, then the
                                              // entries, two entries of read-ahead: 60 bytes
-#ifndef GSR_BWD_DYN_CAP
-#define GSR_BWD_DYN_CAP 253
-#endif
-constexpr int DYN_CAP = GSR_BWD_DYN_CAP;                 // pairs a pass can hold: slot index and record index share a 16-bit list entry,
+constexpr int DYN_CAP = 253;                 // pairs a pass can hold: slot index and record index share a 16-bit list entry,
                                              // a byte each
 struct MbLds {
   struct Rec { float4 A, B; float C; float pad[3]; } R[WAVE + 1];      // one 48-byte record: one address per list entry
@@ -797,10 +794,7 @@ __device__ __forceinline__ void render_bwd_tile_mb16(const int tile, MbLds& L, i
 }
 
 // 13.3 KB of LDS per wave: three blocks of four waves per CU, three waves per SIMD
-#ifndef GSR_BWD_WAVES
-#define GSR_BWD_WAVES 3
-#endif
-constexpr int BWD_WAVES = GSR_BWD_WAVES;
+constexpr int BWD_WAVES = 3;
 __global__ __launch_bounds__(WAVES_PER_BLOCK * WAVE, BWD_WAVES) void render_bwd_kernel(int W, int H, int grid_x, int num_tiles,
                                                           const uint32_t* __restrict__ tile_order,
                                                           const uint2* __restrict__ ranges,
