@@ -511,6 +511,12 @@ def main():
     pkg, _ = train_step()
     R = int(frame_counts(pkg["render"])[0]) if pkg["render"].grad_fn is not None else 0
 
+    # every rank's instance count: the views differ (8.2 M .. 8.6 M instances at C4), and the job is as slow as its slowest rank
+    per_rank_R = torch.zeros(world, dtype=torch.float64, device=dev)
+    per_rank_R[rank] = float(R)
+    if world > 1:
+        all_reduce(per_rank_R, dist.ReduceOp.SUM)
+    per_rank_R = [int(v) for v in per_rank_R.cpu().tolist()]
     if rank == 0:
         tiles = ((W + 15) // 16) * ((H + 15) // 16)
         tb = max(1, (tiles - 1).bit_length())
@@ -651,6 +657,7 @@ def main():
             "train_step_ms_l1_dssim": round(t_dssim / K * 1e3, 3) if extras else None,
             "per_rank_fwd_ms": [round(per_rank[2 * r], 4) for r in range(world)],
             "per_rank_train_ms": [round(per_rank[2 * r + 1], 4) for r in range(world)],
+            "per_rank_instances": per_rank_R,
             "c5_eight_views": c5,
             "profiled_fwd_ms": round(t_fwd_prof / K * 1e3, 3), "profiled_train_ms": round(t_train_prof / K * 1e3, 3),
             "fwd_step_ms_in_order": [round(v, 3) for v in fwd_order], "train_step_ms_in_order": [round(v, 3) for v in train_order],
