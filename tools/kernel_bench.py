@@ -22,8 +22,14 @@ def wide_depth(model):
     model._scaling += torch.log(s_)[:, None]
 
 
+def morton(model):
+    """--morton: the same cloud with its Gaussians stored along a Morton curve (mvs_gaussian_splatting_amd/layout.py)"""
+    from mvs_gaussian_splatting_amd.layout import reorder_gaussians_
+    reorder_gaussians_(model)
+
+
 s = GpuScene(cfg, fused="--fused" in sys.argv,       # --fused: raw parameters + split SH, as render() feeds them
-             mutate=wide_depth if "--wide-depth" in sys.argv else None)
+             mutate=wide_depth if "--wide-depth" in sys.argv else morton if "--morton" in sys.argv else None)
 s.fuse_stats = "--stats" in sys.argv                 # --stats: the backward also takes the densification statistics
 dL = torch.sign(torch.rand(3, s.H, s.W, device=s.dev) - 0.5) / (3 * s.H * s.W)
 for _ in range(2):
