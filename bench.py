@@ -19,7 +19,9 @@ Further regions of the same protocol, reported as extra fields of the same line 
   c5_eight_views         the EIGHT orbit views partitioned {r, r + N, ...} over the N ranks: every rank renders
                          its 8 / N views per round -- at N = 1 the rotating-camera loop (the instance count changes from
                          frame to frame: the capacity-based forward is exercised under a varying R);
-  per_rank_*             every rank's own forward / train ms of the headline regions (gathered).
+  per_rank_*             every rank's own forward / train ms of the headline regions (gathered);
+  morton_layout_*        the same view of the same cloud after layout.reorder_gaussians_ (the Gaussians stored along a Morton
+                         curve: an optional step for callers that own their model; the headline stays on the cloud as generated).
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -517,6 +519,25 @@ def main():
     if world > 1:
         all_reduce(per_rank_R, dist.ReduceOp.SUM)
     per_rank_R = [int(v) for v in per_rank_R.cpu().tolist()]
+    # The same cloud stored along a Morton curve (mvs_gaussian_splatting_amd/layout.py: an optional step a trainer runs
+    # after densify_and_prune).  The headline numbers are measured on SURVEY 8d's cloud as it is generated (uniformly random
+    # index order, the worst case for coherence); this region reports what the layout step is worth on it.  LAST region:
+    # it reorders the model in place.
+    layout = None
+    if extras:
+        from mvs_gaussian_splatting_amd.layout import reorder_gaussians_
+        reorder_gaussians_(model)
+        for prm in model.parameters():
+            prm.requires_grad_(True)
+        fwd_step(); train_step()
+        for _ in range(prewarm["fwd"]):              # the headline regions' protocol: the same untimed steps in front
+            fwd_step()
+        t_lf, _ = timed(fwd_step, K)
+        for _ in range(prewarm["train"]):
+            train_step()
+        t_lt, _ = timed(train_step, K)
+        layout = {"morton_layout_fwd_ms": round(t_lf / K * 1e3, 3), "morton_layout_train_ms": round(t_lt / K * 1e3, 3),
+                  "morton_layout_mpixels_per_s": round(world * W * H / (t_lf / K) / 1e6, 1)}
     if rank == 0:
         tiles = ((W + 15) // 16) * ((H + 15) // 16)
         tb = max(1, (tiles - 1).bit_length())
@@ -697,6 +718,8 @@ def main():
         line.update(readback)
         if unfused:
             line.update(unfused)
+        if layout:
+            line.update(layout)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(cfg, args.seed)

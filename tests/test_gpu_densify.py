@@ -133,3 +133,26 @@ def test_densify_rejects_cpu_and_bad_noise(dev):
     m = _Model(2000, 1, dev, False)
     with pytest.raises(ValueError, match="noise must be"):
         densify_and_prune(m, 0.0002, 0.005, 5.0, 20, noise=torch.zeros(1, 3, device=dev))
+
+
+def test_densify_in_spatial_order_is_the_reference_result_permuted(dev):
+    """``spatial_order=True`` (this build's extension): the Gaussians, their Adam moments and the reset statistics of the
+    reference-order result, stored along the Morton curve of the new positions."""
+    from mvs_gaussian_splatting_amd.densify import densify_and_prune
+    from mvs_gaussian_splatting_amd.layout import morton_permutation
+    from oracle.densify_ref import count_split_selected_ref
+    a, b = _Model(3000, 21, dev, True), _Model(3000, 21, dev, True)
+    n_sel = count_split_selected_ref(a.cpu_params, a.cpu_accum.clone(), a.cpu_denom, a.percent_dense, 0.0002, 5.0)
+    noise = torch.randn(2 * n_sel, 3, generator=torch.Generator().manual_seed(5)).to(dev)
+    ia = densify_and_prune(a, 0.0002, 0.005, 5.0, 20, noise=noise)
+    ib = densify_and_prune(b, 0.0002, 0.005, 5.0, 20, noise=noise, spatial_order=True)
+    assert ia == ib and ia["cloned"] > 0 and ia["split_selected"] > 0
+    perm = morton_permutation(a._xyz)
+    assert not torch.equal(perm, torch.arange(perm.numel(), device=dev))
+    for k in GROUPS:
+        pa, pb = getattr(a, ATTR[k]), getattr(b, ATTR[k])
+        assert isinstance(pb, torch.nn.Parameter) and pb.requires_grad
+        assert torch.equal(pb.detach(), pa.detach()[perm])
+        sa, sb = a.optimizer.state[pa], b.optimizer.state[pb]
+        assert torch.equal(sb["exp_avg"], sa["exp_avg"][perm]) and torch.equal(sb["exp_avg_sq"], sa["exp_avg_sq"][perm])
+    assert b.xyz_gradient_accum.shape == a.xyz_gradient_accum.shape and not b.xyz_gradient_accum.any()
