@@ -13,7 +13,8 @@ it along a 30-bit Morton curve of the positions, with the Adam-moment surgery of
 Results are the unpermuted model's up to the permutation: every per-Gaussian quantity is computed from that Gaussian's
 row alone, and a tile's list is ordered by depth.  Only equal-depth ties inside a tile (broken by index, as in the
 reference's stable sort) can blend in another order; a frame without such ties is bit-identical, gradients included
-(``tests/test_gpu_layout.py``).  Measured on the 6 M-Gaussian bench cloud, whose index order is uniformly random:
+(``tests/test_gpu_layout.py``; at 6 M Gaussians the sorted keys are the same array, 882 of 8.2 M list entries swap places
+inside equal-key runs and 279 of 2 M pixels differ, by at most 1.2e-3).  Measured on the 6 M-Gaussian bench cloud, whose index order is uniformly random:
 forward 0.912 -> 0.846 ms, train step 2.252 -> 2.056 ms (``profiles/r04/layout_morton.txt``).
 """
 from __future__ import annotations
