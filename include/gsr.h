@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 12
+#define GSR_ABI_VERSION 13
 
 enum {
   GSR_OK = 0,
@@ -82,6 +82,14 @@ typedef struct GsrParams {
   uint8_t* visible_out;        /* NULL, or device [P] (ABI v12): the forward also stores radii[i] > 0 there -- the
                                   `visibility_filter = radii > 0` of the reference's render()
                                   (gaussian_renderer/__init__.py:311) without a pass of its own over the radii */
+  int32_t depth_span_lt24;     /* gsr_forward only (ABI v13).  1: the caller expects the frame's depth keys (float32 bits of the
+                                  view depths of the visible Gaussians) to span fewer than 2^24 steps -- counts_pinned[3] -
+                                  counts_pinned[2] < 2^24, about two binades of depth -- and the depth sort's fourth pass (three
+                                  launches that find nothing to do on such a frame) is NOT enqueued.  The caller must check
+                                  the two words once the counts event has completed, exactly as it checks the capacity: a
+                                  frame that spans more is sorted on its low 24 key bits only (no out-of-bounds access,
+                                  but lists in the wrong depth order) and must be discarded / redone with 0.
+                                  0: the pass is enqueued and decides on the device (any frame is right). */
 } GsrParams;
 
 enum {
@@ -166,6 +174,7 @@ int gsr_forward_render(const GsrParams* p, void* geom_ws, void* bin_ws, size_t b
  *   Overflow     : when num_rendered > capacity the instances past the capacity are dropped (no out-of-bounds
  *                  access, but the image and every gradient of the frame are INCOMPLETE): the caller must compare
  *                  counts_pinned[0] with its capacity once the event has completed and discard / redo the frame.
+ *   Depth span   : with p->depth_span_lt24 = 1 the same check covers counts_pinned[3] - counts_pinned[2] < 2^24 (see the field).
  *   Backward     : call gsr_backward with num_rendered = capacity and num_visible = P (the values the workspaces
  *                  were laid out with); gsr_backward_bytes(P, capacity) sizes its workspace.
  * Only GSR_BINNING_TWO_LEVEL / _CULLED (the 64-bit key mode keeps the two-call path). */

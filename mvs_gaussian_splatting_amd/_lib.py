@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # instead of copying it over the in-tree library
 LIB_PATH = os.environ.get("GSR_LIB_PATH") or os.path.join(_HERE, "libgsr_hip.so")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class GsrParams(C.Structure):
@@ -29,7 +29,7 @@ class GsrParams(C.Structure):
         ("campos", C.c_void_p), ("bg", C.c_void_p), ("profile", C.c_void_p),
         ("shs_rest", C.c_void_p), ("act_flags", C.c_int32), ("binning_mode", C.c_int32),
         ("counts_pinned", C.c_void_p), ("forward_only", C.c_int32), ("debug_flags", C.c_int32),
-        ("visible_out", C.c_void_p),
+        ("visible_out", C.c_void_p), ("depth_span_lt24", C.c_int32),
     ]
 
 

@@ -95,17 +95,20 @@ __global__ __launch_bounds__(PRE_BLOCK) void compact_visible_kernel(int P, const
                                                                     int grid_x,
                                                                     uint32_t* __restrict__ dkey,
                                                                     uint2* __restrict__ dval,
-                                                                    uint32_t* __restrict__ total, uint32_t capacity) {
+                                                                    uint32_t* __restrict__ total, uint32_t capacity,
+                                                                    int top_pass_enqueued) {
   __shared__ uint32_t wave_tot[PRE_BLOCK / WAVE];
   __shared__ uint32_t wave_tiles[PRE_BLOCK / WAVE];
   const uint32_t min_bits = ~*depth_inv_min;      // smallest depth key of the frame: keys are sorted relative to it
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // counts the later stages read from the device (total = [R, V, big, -, ~min depth key, max depth key, ...]):
     //   [6] elements of the depth sort's top-digit pass: V when the frame spans more than 2^DEPTH_SORT_BITS depth keys
-    //       (the pass then runs and the sorted payload ends in the other buffer), else 0 (its kernels exit at once)
+    //       (the pass then runs and the sorted payload ends in the other buffer), else 0 (its kernels exit at once);
+    //       always 0 when the caller did not enqueue the pass (GsrParams::depth_span_lt24): the consumers then read the
+    //       buffer the three regular passes ended in, whatever the span -- the caller discards such a frame
     //   [7] instances the binning workspace really receives: min(R, capacity)
     const uint32_t R = total[TOTAL_R], V = total[TOTAL_V], mx = total[TOTAL_DEPTH_MAX];
-    const bool top = V > 0u && mx >= min_bits && ((mx - min_bits) >> DEPTH_SORT_BITS) != 0u;
+    const bool top = top_pass_enqueued && V > 0u && mx >= min_bits && ((mx - min_bits) >> DEPTH_SORT_BITS) != 0u;
     total[TOTAL_TOP_PASS_N] = top ? V : 0u;
     total[TOTAL_R_CLAMPED] = min(R, capacity);
   }
@@ -966,11 +969,11 @@ bool launch_sort_pairs_u32_v64(uint32_t* keys_a, uint2* vals_a, uint32_t* keys_b
 
 void launch_compact_visible(int P, const BinInfo* bin, const uint32_t* block_vis_offs, const uint32_t* block_offs,
                             uint32_t* slot_base, uint32_t* total, uint32_t capacity, int grid_x, uint32_t* dkey,
-                            uint2* dval, hipStream_t s) {
+                            uint2* dval, hipStream_t s, bool top_pass_enqueued) {
   const int nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
   if (nb > 0)
     hipLaunchKernelGGL(compact_visible_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, P, bin, block_vis_offs, block_offs, slot_base,
-                       total + TOTAL_DEPTH_INV_MIN, grid_x, dkey, dval, total, capacity);
+                       total + TOTAL_DEPTH_INV_MIN, grid_x, dkey, dval, total, capacity, top_pass_enqueued ? 1 : 0);
 }
 // one more pass on bits [shift, shift + nbits) of 32-bit keys (nbits <= 8): the top digit of the depth sort
 void launch_sort_extra_pass_u32(const uint32_t* kin, const uint2* vin, uint32_t* kout, uint2* vout, uint32_t n,

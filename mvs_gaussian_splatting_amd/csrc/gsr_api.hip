@@ -209,8 +209,12 @@ static void enqueue_depth_top_pass(const GsrParams* p, void* geom_ws, hipStream_
 // Stage 1 on the stream: preprocess, scan of the block totals (counts -> total[] and the pinned mirror), `counted`
 // recorded behind the scan, then -- two-level modes -- compaction of the visible Gaussians and their depth sort.
 // None of it needs a host-side count: the grids are sized for P and the kernels read V from the device.
+// top_pass: WITH = enqueued here, decides on the device (gsr_forward); LATER = the host enqueues it behind stage 1 for the
+// frames that need it (two-call path, which knows the span); NEVER = the caller vouches for a narrow frame
+// (GsrParams::depth_span_lt24): the device-side switch stays off whatever the span.
+enum TopPass { TOP_PASS_WITH, TOP_PASS_LATER, TOP_PASS_NEVER };
 static int enqueue_stage1(const GsrParams* p, void* geom_ws, int32_t* radii, hipStream_t s, uint32_t capacity,
-                          hipEvent_t counted, bool top_pass) {
+                          hipEvent_t counted, TopPass top_pass) {
   const GeomLayout L(p->P);
   {
     StageTimer t(p, GSR_STAGE_PREPROCESS_FWD, s);
@@ -234,11 +238,12 @@ static int enqueue_stage1(const GsrParams* p, void* geom_ws, int32_t* radii, hip
     launch_compact_visible(p->P, at<BinInfo>(geom_ws, L.bin), at<uint32_t>(geom_ws, L.block_vis_offs),
                            at<uint32_t>(geom_ws, L.block_offs),
                            p->forward_only ? nullptr : at<uint32_t>(geom_ws, L.slot_base), total, capacity,
-                           (p->width + TILE - 1) / TILE, at<uint32_t>(geom_ws, L.dkey_a), at<uint2>(geom_ws, L.didx_a), s);
+                           (p->width + TILE - 1) / TILE, at<uint32_t>(geom_ws, L.dkey_a), at<uint2>(geom_ws, L.didx_a), s,
+                           top_pass != TOP_PASS_NEVER);
     launch_sort_pairs_u32_v64(at<uint32_t>(geom_ws, L.dkey_a), at<uint2>(geom_ws, L.didx_a),
                               at<uint32_t>(geom_ws, L.dkey_b), at<uint2>(geom_ws, L.didx_b), (uint32_t)p->P,
                               DEPTH_SORT_BITS, at<char>(geom_ws, L.dsort), s, total + TOTAL_V);
-    if (top_pass) enqueue_depth_top_pass(p, geom_ws, s);
+    if (top_pass == TOP_PASS_WITH) enqueue_depth_top_pass(p, geom_ws, s);
   }
   return check(p, s, "depth_sort");
 }
@@ -384,7 +389,7 @@ int gsr_forward_preprocess(const GsrParams* p, void* geom_ws, int32_t* radii, vo
   if (p->counts_pinned) GSR_HIP(g_count_event.get(&counted));
   // the first half of the two-level binning is enqueued before the read-back, so that the GPU sorts while the host
   // round-trips; the top-digit pass follows only for the frames that need it (the host knows once the counts are in)
-  if (int rc = enqueue_stage1(p, geom_ws, radii, s, 0xffffffffu, counted, false)) return rc;
+  if (int rc = enqueue_stage1(p, geom_ws, radii, s, 0xffffffffu, counted, TOP_PASS_LATER)) return rc;
   uint32_t depth_min = 0, depth_max = 0;
   if (counted) {
     const hipError_t e = hipEventSynchronize(counted);     // waits for the scan kernel only
@@ -431,7 +436,10 @@ int gsr_forward(const GsrParams* p, void* geom_ws, void* bin_ws, size_t bin_ws_b
   if (p->P > 0) {
     if (!geom_ws || !radii) return fail(GSR_E_BADARG, "geom_ws / radii is NULL");
     if (((uintptr_t)geom_ws & 255u) != 0) return fail(GSR_E_ALIGN, "geom_ws must be 256-byte aligned");
-    if (int rc = enqueue_stage1(p, geom_ws, radii, s, capacity, static_cast<hipEvent_t>(counts_event), true)) return rc;
+    // the depth sort's fourth pass: enqueued (and decided on the device) unless the caller vouches for a narrow frame
+    if (int rc = enqueue_stage1(p, geom_ws, radii, s, capacity, static_cast<hipEvent_t>(counts_event),
+                                p->depth_span_lt24 ? TOP_PASS_NEVER : TOP_PASS_WITH))
+      return rc;
   } else if (counts_event) {
     GSR_HIP(hipEventRecord(static_cast<hipEvent_t>(counts_event), s));
   }

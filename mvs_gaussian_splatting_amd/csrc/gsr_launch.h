@@ -51,9 +51,10 @@ void launch_build_tile_order(int tiles, const uint2* ranges, uint32_t* order, hi
 void launch_ranges_and_order_from_sort(int tiles, const SortedRuns& sr, uint2* ranges, uint32_t* order, hipStream_t s);
 // also derives the device-side counts of the later stages (GeomLayout::total[TOTAL_TOP_PASS_N / TOTAL_R_CLAMPED]);
 // capacity: instances the binning workspace holds (0xffffffff when the host sizes it from the real count)
+// top_pass_enqueued = false: total[TOTAL_TOP_PASS_N] stays 0 whatever the frame's depth span (nobody will run the pass)
 void launch_compact_visible(int P, const BinInfo* bin, const uint32_t* block_vis_offs, const uint32_t* block_offs,
                             uint32_t* slot_base, uint32_t* total, uint32_t capacity, int grid_x, uint32_t* dkey,
-                            uint2* dval, hipStream_t s);
+                            uint2* dval, hipStream_t s, bool top_pass_enqueued = true);
 // (32-bit key, 64-bit value) pairs: the depth sort, whose payload is (index, packed rect)
 bool launch_sort_pairs_u32_v64(uint32_t* keys_a, uint2* vals_a, uint32_t* keys_b, uint2* vals_b, uint32_t n,
                                int end_bit, void* scratch, hipStream_t s, const uint32_t* n_dev = nullptr);

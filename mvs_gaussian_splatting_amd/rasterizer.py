@@ -185,6 +185,7 @@ def _make_params(dev, settings: GaussianRasterizationSettings, means3D, sh, colo
     p.forward_only = int(bool(forward_only))
     p.debug_flags = _debug_flags_value
     p.visible_out = None
+    p.depth_span_lt24 = 0
     return p, [bg, view, proj, campos]
 
 
@@ -197,18 +198,22 @@ def _round_ws(nbytes: int) -> int:
 
 # ---- instance capacity of the frames issued without a count read-back ------------------------------------------------
 class _CapacityState:
-    """Per (device, P, W, H, binning mode): the instance capacity later frames are issued with, and the workspaces
+    """Per (device, P, W, H, binning mode): the instance capacity later frames are issued with, the widest depth-key span
+    seen (frames are issued without the depth sort's fourth pass while it stays clearly below 2^24), and the workspaces
     forward-only frames share (nothing reads them after the frame: a fresh allocation per frame is pure host time)."""
-    __slots__ = ("capacity", "last_counts", "fo_ws", "reissued")
+    __slots__ = ("capacity", "last_counts", "depth_span", "fo_ws", "reissued")
 
     def __init__(self):
         self.capacity = 0
         self.last_counts = (0, 0)
+        self.depth_span = 0     # largest (max depth key - min depth key) of the frames seen
         self.fo_ws = {}         # stream handle -> (capacity, geom, img, binning) of the forward-only frames on that stream
         self.reissued = 0       # frames that did not fit their capacity and were issued again (verified mode)
 
-    def observe(self, R: int, V: int) -> None:
+    def observe(self, R: int, V: int, span: int = 0) -> None:
         self.last_counts = (R, V)
+        if span > self.depth_span:
+            self.depth_span = span
         want = (int(R * 1.5) + (1 << 20)) >> 20 << 20       # 1.5 x, in steps of 2^20 instances
         if R > 0 and want > self.capacity:
             self.capacity = want
@@ -409,6 +414,16 @@ class _Frame(NamedTuple):
     counts: Optional[tuple]         # the real (num_rendered, num_visible) when known
 
 
+_DEPTH_SORT_BITS = 24                                   # csrc/gsr_common.h: the depth sort's three regular 8-bit passes
+_DEPTH_SPAN_TRUSTED = int(0.9 * (1 << _DEPTH_SORT_BITS))
+
+
+def _depth_span(words, V: int) -> int:
+    """max - min depth key of a frame from its pinned counts (0 for a frame without visible Gaussians)."""
+    mn, mx = int(words[2]), int(words[3])
+    return mx - mn if V > 0 and mx >= mn else 0
+
+
 def _run_forward(lib, dev, params, P: int, W: int, H: int):
     """Native forward on torch's current stream.  Returns (color, _Frame)."""
     stream = _stream(dev)
@@ -452,20 +467,27 @@ def _run_forward(lib, dev, params, P: int, W: int, H: int):
             with _defer_lock:
                 _pending.append(pend)
             return color, _Frame(geom, binning, img, radii, cap, P, pend, None)
-        # verified mode: the whole frame is queued, the host waits for its scan kernel only
+        # verified mode: the whole frame is queued, the host waits for its scan kernel only.  Two things are taken on trust
+        # from the frames before and checked against the counts: the instance capacity, and -- while every frame seen
+        # stayed below 0.9 x 2^24 depth-key steps -- that the depth sort needs no fourth pass (GsrParams.depth_span_lt24:
+        # three launches that find nothing to do, 14 us of a 6 M-Gaussian frame and 9 us of a 100 k one).
         pinned, words = _counts_pinned_thread()
         params.counts_pinned = pinned.data_ptr()
+        narrow = st.depth_span < _DEPTH_SPAN_TRUSTED
+        params.depth_span_lt24 = 1 if narrow else 0
         event = _thread_event(dev_index)
         _lib.check(lib.gsr_forward(C.byref(params), geom.data_ptr(), binning.data_ptr(), nbytes, cap, img.data_ptr(),
                                    radii.data_ptr(), color.data_ptr(), event, stream), "gsr_forward")
         _lib.check(lib.gsr_event_wait(event), "gsr_event_wait")
+        params.depth_span_lt24 = 0
         R, V = int(words[0]), int(words[1])
-        st.observe(R, V)
-        if R <= cap:
+        span = _depth_span(words, V)
+        st.observe(R, V, span)
+        if R <= cap and not (narrow and span >> _DEPTH_SORT_BITS):
             return color, _Frame(geom, binning, img, radii, cap, P, None, (R, V))
-        # The frame did not fit: its kernels dropped the instances past the capacity (no out-of-bounds access) and are
-        # still running.  Issue it again behind them, on the two-call path, into the same outputs -- nothing of the
-        # truncated frame has left the operator.
+        # The frame did not fit (its kernels dropped the instances past the capacity: no out-of-bounds access), or spans
+        # more depth than it was sorted for (lists in the wrong order), and is still running.  Issue it again behind
+        # itself, on the two-call path, into the same outputs -- nothing of the wrong frame has left the operator.
         st.reissued += 1
         if params.forward_only:
             with _defer_lock:
@@ -476,7 +498,7 @@ def _run_forward(lib, dev, params, P: int, W: int, H: int):
     _lib.check(lib.gsr_forward_preprocess(C.byref(params), geom.data_ptr(), _ptr(radii), stream,
                                           C.byref(num_rendered), C.byref(num_visible)), "gsr_forward_preprocess")
     R, V = int(num_rendered.value), int(num_visible.value)
-    st.observe(R, V)
+    st.observe(R, V, _depth_span(_words, V))
     nbytes = lib.gsr_binning_bytes(R, V, W, H, mode)
     binning = torch.empty(_round_ws(nbytes), dtype=torch.uint8, device=dev)
     _lib.check(lib.gsr_forward_render(C.byref(params), geom.data_ptr(), binning.data_ptr(), nbytes, img.data_ptr(),

@@ -18,9 +18,12 @@ def product_settings(cam, bg, sh_degree, dev, scale_modifier=1.0, debug=False):
 
 
 def forward_with_state(dev, settings, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                       cov3D_precomp=None, binning_mode=None, want_stats=False, sync_free_capacity=None):
+                       cov3D_precomp=None, binning_mode=None, want_stats=False, sync_free_capacity=None,
+                       depth_span_lt24=False):
     """Forward through the C ABI keeping the workspaces; returns a dict of numpy/torch results.
-    sync_free_capacity: run gsr_forward (no count read-back) with that instance capacity instead of the two calls."""
+    sync_free_capacity: run gsr_forward (no count read-back) with that instance capacity instead of the two calls;
+    depth_span_lt24: ... and without the depth sort's fourth pass (GsrParams.depth_span_lt24; "depth_keys" in the result
+    is what the caller has to check)."""
     lib = _lib.load()
     e = torch.empty(0, dtype=torch.float32, device=dev)
     f = lambda t: e if t is None else t.to(dev).float().contiguous()  # noqa: E731
@@ -36,6 +39,7 @@ def forward_with_state(dev, settings, means3D, opacities, shs=None, colors_preco
         radii = torch.zeros(P, dtype=torch.int32, device=dev)
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
         R, V = C.c_uint32(0), C.c_uint32(0)
+        depth_keys = None
         # the list-level parity tests speak about the un-culled lists unless a mode is asked for
         params.binning_mode = _lib.BINNING_TWO_LEVEL if binning_mode is None else binning_mode
         if sync_free_capacity is None:
@@ -51,12 +55,14 @@ def forward_with_state(dev, settings, means3D, opacities, shs=None, colors_preco
             cap = int(sync_free_capacity)
             pinned = torch.zeros(16, dtype=torch.int32).pin_memory()
             params.counts_pinned = pinned.data_ptr()
+            params.depth_span_lt24 = 1 if depth_span_lt24 else 0
             nb = lib.gsr_binning_bytes(cap, P, W, H, params.binning_mode)
             binning = torch.empty(nb, dtype=torch.uint8, device=dev)
             _lib.check(lib.gsr_forward(C.byref(params), geom.data_ptr(), binning.data_ptr(), nb, cap, img.data_ptr(),
                                        radii.data_ptr(), color.data_ptr(), None, stream), "gsr_forward")
             torch.cuda.synchronize(dev)
             R, V = int(pinned[0]) & 0xffffffff, int(pinned[1]) & 0xffffffff
+            depth_keys = (int(pinned[2]) & 0xffffffff, int(pinned[3]) & 0xffffffff)
             assert R <= cap, "test asked for a capacity below the instance count"
             lay_R, lay_V = cap, P       # what the workspaces are laid out for
         xy = torch.empty(P, 2, device=dev)
@@ -100,7 +106,7 @@ def forward_with_state(dev, settings, means3D, opacities, shs=None, colors_preco
             assert torch.equal(scratch, color)
         torch.cuda.synchronize(dev)
     del keep
-    return {"counts": [int(v) for v in cnt], "stats": stats, "color": color.cpu(), "radii": radii.cpu(), "R": R, "V": V, "xy": xy.cpu(), "conic_opacity": con.cpu(),
+    return {"counts": [int(v) for v in cnt], "stats": stats, "depth_keys": depth_keys, "color": color.cpu(), "radii": radii.cpu(), "R": R, "V": V, "xy": xy.cpu(), "conic_opacity": con.cpu(),
             "rgb": rgb.cpu(), "depth": depth.cpu(), "tiles": tiles.cpu().numpy().astype(np.int64),
             "offsets": offs.cpu().numpy().view(np.uint32), "rect": rect.cpu().numpy().astype(np.int64),
             "clamped": clamped.cpu().numpy(), "keys": keys[:R].cpu().numpy().view(np.uint64),

@@ -66,7 +66,8 @@ def test_eight_view_train_steps_never_raise_and_equal_the_per_frame_readback(gpu
                 add_densification_stats(model, pkg["viewspace_points"], pkg["radii"])
                 sums = [bits_checksum(pkg["render"]), bits_checksum(pkg["radii"]), bits_checksum(pkg["viewspace_points"].grad)]
                 sums += [bits_checksum(p.grad) for p in model.parameters()]
-                out.append((rz.frame_counts(pkg["render"]), sums))
+                words = rz._counts_pinned_thread()[1]                      # this frame's (R, V, min depth key, max depth key)
+                out.append((rz.frame_counts(pkg["render"]), sums, int(words[3]) - int(words[2])))
             stats = [bits_checksum(t) for t in (model.xyz_gradient_accum, model.denom, model.max_radii2D)]
             reissued = rz.reissued_frames(gpu_device, P, cfg.width, cfg.height)
         finally:
@@ -81,11 +82,16 @@ def test_eight_view_train_steps_never_raise_and_equal_the_per_frame_readback(gpu
     sq, sq_stats, sq_reissued = run(True, squeeze_to=1 << 20)      # 2^20 instances: every frame after the first overflows
     print(f"[C5 views] frames issued twice: natural capacity {nat_reissued}, forced capacity {sq_reissued}")
     assert sq_reissued == N_VIEWS - 1
-    # a view whose count exceeds 1.5 x everything before it must have been re-issued in the natural run
-    must = sum(1 for i in range(1, N_VIEWS) if counts[i] > ((int(max(counts[:i]) * 1.5) + (1 << 20)) >> 20 << 20))
+    # a view whose count exceeds 1.5 x everything before it, or which spans 2^24 depth-key steps when every view before it
+    # stayed below 0.9 x 2^24 (it was issued without the depth sort's fourth pass), must have been re-issued in the natural run
+    spans = [c[2] for c in ref]
+    print(f"[C5 views] depth-key spans / 2^24: {[round(sp / (1 << 24), 3) for sp in spans]}")
+    must = sum(1 for i in range(1, N_VIEWS)
+               if counts[i] > ((int(max(counts[:i]) * 1.5) + (1 << 20)) >> 20 << 20)
+               or (max(spans[:i]) < rz._DEPTH_SPAN_TRUSTED and spans[i] >> 24))
     assert nat_reissued == must
     for got, got_stats in ((nat, nat_stats), (sq, sq_stats)):
-        for v, ((cnt, sums), (cnt0, sums0)) in enumerate(zip(got, ref)):
+        for v, ((cnt, sums, _), (cnt0, sums0, _)) in enumerate(zip(got, ref)):
             assert cnt == cnt0, f"view {v}: counts {cnt} != {cnt0}"
             assert sums == sums0, f"view {v}: image / radii / gradients differ from the per-frame read-back"
         assert got_stats == ref_stats

@@ -119,6 +119,66 @@ def test_raw_abi_lists_and_state_are_those_of_the_two_call_path(gpu_device):
                 assert np.array_equal(out["ranges"], ref["ranges"])
                 for k in ("color", "final_T", "n_contrib", "radii"):
                     assert torch.equal(out[k], ref[k]), k
+            # GsrParams.depth_span_lt24 (ABI v13): the frame goes without the depth sort's fourth pass.  A narrow frame
+            # is the same frame; a wide one is reported through the two depth keys (the caller discards it) and touches
+            # nothing out of bounds: same counts, the same Gaussians in every tile, only their order is not the depth order.
+            out = forward_with_state(gpu_device, st, model.get_xyz, model.get_opacity, binning_mode=mode,
+                                     sync_free_capacity=ref["R"] + 7, depth_span_lt24=True, **kw)
+            lo, hi = out["depth_keys"]
+            assert (out["R"], out["V"]) == (ref["R"], ref["V"]) and hi >= lo
+            assert ((hi - lo) >> 24 != 0) == wide
+            assert np.array_equal(out["ranges"], ref["ranges"]) and torch.equal(out["radii"], ref["radii"])
+            if not wide:
+                assert np.array_equal(out["point_list"], ref["point_list"]) and np.array_equal(out["keys"], ref["keys"])
+                for k in ("color", "final_T", "n_contrib"):
+                    assert torch.equal(out[k], ref[k]), k
+            else:
+                assert not np.array_equal(out["point_list"], ref["point_list"])
+                tile_of = (ref["keys"] >> np.uint64(32)).astype(np.int64)
+                a = np.lexsort((ref["point_list"], tile_of))
+                b = np.lexsort((out["point_list"], tile_of))
+                assert np.array_equal(ref["point_list"][a], out["point_list"][b])
+
+
+def test_a_frame_that_spans_more_depth_than_the_frames_before_is_issued_again(gpu_device, fresh_state):
+    """Verified mode issues frames without the depth sort's fourth pass while every frame seen stayed below 0.9 x 2^24
+    depth-key steps.  The first frame that spans more is caught by the counts check and issued again before the operator
+    returns (bit-identical to the per-frame read-back); from then on the pass is enqueued and nothing is re-issued."""
+    rz = fresh_state
+    narrow = _scene(gpu_device)
+    wide = _scene(gpu_device, wide_depth=True)
+    P, (W, H) = narrow[0]._xyz.shape[0], (narrow[1].image_width, narrow[1].image_height)
+    prev = rz.set_sync_free(False)
+    ref_n, gref_n = _step(*narrow)
+    ref_w, gref_w = _step(*wide)
+    rz.set_sync_free(prev)
+    rz._states.clear()
+    _step(*narrow)                                               # two-call path: learns capacity and span
+    st = next(iter(rz._states.values()))
+    assert 0 < st.depth_span < rz._DEPTH_SPAN_TRUSTED
+    st.capacity = 1 << 22                                        # room for the wide cloud: only the span is at stake
+    pkg, g = _step(*narrow)                                      # issued without the fourth pass
+    assert rz.reissued_frames(gpu_device, P, W, H) == 0
+    assert torch.equal(pkg["render"], ref_n["render"]) and all(torch.equal(a, b) for a, b in zip(g, gref_n))
+    pkg, g = _step(*wide)                                        # spans 23 binades: caught, issued again
+    assert rz.reissued_frames(gpu_device, P, W, H) == 1 and st.depth_span >> 24
+    assert rz.frame_counts(pkg["render"]) == rz.frame_counts(ref_w["render"])
+    assert torch.equal(pkg["render"], ref_w["render"]) and torch.equal(pkg["radii"], ref_w["radii"])
+    assert all(torch.equal(a, b) for a, b in zip(g, gref_w))
+    for scene, ref, gref in ((wide, ref_w, gref_w), (narrow, ref_n, gref_n), (wide, ref_w, gref_w)):
+        pkg, g = _step(*scene)                                   # the pass is enqueued from now on: any frame is right
+        assert torch.equal(pkg["render"], ref["render"]) and all(torch.equal(a, b) for a, b in zip(g, gref))
+    assert rz.reissued_frames(gpu_device, P, W, H) == 1
+    with torch.no_grad():                                        # forward-only frames take the same route
+        from mvs_gaussian_splatting_amd import render
+        from mvs_gaussian_splatting_amd.synthetic import PipelineParams
+        rz._states.clear()
+        a = render(narrow[1], narrow[0], PipelineParams(), narrow[2])["render"]
+        next(iter(rz._states.values())).capacity = 1 << 22
+        b = render(wide[1], wide[0], PipelineParams(), wide[2])["render"]
+        c = render(wide[1], wide[0], PipelineParams(), wide[2])["render"]
+    assert torch.equal(a, ref_n["render"].detach()) and torch.equal(b, ref_w["render"].detach()) and torch.equal(c, b)
+    assert rz.reissued_frames(gpu_device, P, W, H) == 1
 
 
 def _views(P, n=4, **kw):

@@ -75,3 +75,16 @@ t1.record()
 torch.cuda.synchronize()
 wall = (__import__("time").perf_counter() - wall0) * 1e3 / iters
 print(f"sync-free forward: {t0.elapsed_time(t1) / iters:.3f} ms per frame on the device, {wall:.3f} ms wall (back to back, capacity {s.cap})")
+# ... and without the depth sort's fourth pass (GsrParams.depth_span_lt24: what the operator issues while the frames it has
+# seen span fewer than 0.9 x 2^24 depth-key steps)
+if "--wide-depth" not in sys.argv:
+    s.params.depth_span_lt24 = 1
+    s.forward_sync_free()
+    torch.cuda.synchronize()
+    t0.record()
+    for _ in range(iters):
+        s.forward_sync_free()
+    t1.record()
+    torch.cuda.synchronize()
+    s.params.depth_span_lt24 = 0
+    print(f"sync-free forward, depth_span_lt24: {t0.elapsed_time(t1) / iters:.3f} ms per frame on the device")
