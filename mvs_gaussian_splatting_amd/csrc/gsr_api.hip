@@ -220,7 +220,7 @@ static int enqueue_stage1(const GsrParams* p, void* geom_ws, int32_t* radii, hip
     StageTimer t(p, GSR_STAGE_PREPROCESS_FWD, s);
     launch_preprocess_fwd(*p, at<GeomRec>(geom_ws, L.rec), at<BinInfo>(geom_ws, L.bin),
                           at<uint32_t>(geom_ws, L.block_sums), at<uint32_t>(geom_ws, L.block_vis), radii,
-                          at<uint32_t>(geom_ws, L.total) + TOTAL_BIG, at<uint32_t>(geom_ws, L.big_list),
+                          at<uint32_t>(geom_ws, L.block_big), at<uint32_t>(geom_ws, L.big_list),
                           at<uint2>(geom_ws, L.block_range), s);
   }
   if (int rc = check(p, s, "preprocess_fwd")) return rc;
@@ -229,7 +229,8 @@ static int enqueue_stage1(const GsrParams* p, void* geom_ws, int32_t* radii, hip
     StageTimer t(p, GSR_STAGE_SCAN, s);
     launch_scan_block_sums(at<uint32_t>(geom_ws, L.block_sums), at<uint32_t>(geom_ws, L.block_offs), total + TOTAL_R,
                            at<uint32_t>(geom_ws, L.block_vis), at<uint32_t>(geom_ws, L.block_vis_offs), total + TOTAL_V,
-                           L.nblocks, s, p->counts_pinned, at<uint2>(geom_ws, L.block_range));
+                           L.nblocks, s, p->counts_pinned, at<uint2>(geom_ws, L.block_range),
+                           at<uint32_t>(geom_ws, L.block_big), at<uint32_t>(geom_ws, L.block_big_offs), total + TOTAL_BIG);
   }
   if (int rc = check(p, s, "scan_block_sums")) return rc;
   if (counted) GSR_HIP(hipEventRecord(counted, s));
@@ -540,8 +541,8 @@ int gsr_backward(const GsrParams* p, const int32_t* radii, const void* geom_ws, 
   }
   {
     StageTimer t(p, GSR_STAGE_PREPROCESS_BWD, s);
-    launch_sum_big_rows(at<uint32_t>(geom_ws, L.total) + 2, at<uint32_t>(geom_ws, L.big_list), rec,
-                        at<uint32_t>(geom_ws, L.slot_base), rows, flags, s);
+    launch_sum_big_rows(at<uint32_t>(geom_ws, L.total) + TOTAL_BIG, at<uint32_t>(geom_ws, L.block_big_offs), L.nblocks,
+                        at<uint32_t>(geom_ws, L.big_list), rec, at<uint32_t>(geom_ws, L.slot_base), rows, flags, s);
     launch_preprocess_bwd(*p, radii, rec, at<uint32_t>(geom_ws, L.slot_base), rows, flags, *grads, s);
   }
   return check(p, s, "preprocess_bwd");

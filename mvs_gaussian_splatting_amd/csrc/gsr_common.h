@@ -135,7 +135,7 @@ struct SortLayout {
 
 struct GeomLayout {
   size_t rec, bin, offsets, slot_base, block_sums, block_offs, block_vis, block_vis_offs, block_range, total;
-  size_t dkey_a, dkey_b, didx_a, didx_b, dsort, big_list, bytes;   // depth sort of the visible Gaussians (capacity P)
+  size_t dkey_a, dkey_b, didx_a, didx_b, dsort, big_list, block_big, block_big_offs, bytes;   // depth sort of the visible Gaussians (capacity P)
   int nblocks;
   __host__ __device__ explicit GeomLayout(int P) {
     nblocks = (P + PRE_BLOCK - 1) / PRE_BLOCK;
@@ -155,7 +155,12 @@ struct GeomLayout {
     didx_a = o;     o = align_up(o + 8 * (size_t)P, 256);    // payload: (index, packed rect)
     didx_b = o;     o = align_up(o + 8 * (size_t)P, 256);
     dsort = o;      o = align_up(o + SortLayout((uint32_t)(P > 0 ? P : 1)).bytes, 256);
-    big_list = o;   o = align_up(o + 4 * (size_t)P, 256);    // Gaussians with more than ROWS_COOP instances (any order)
+    // Gaussians with more than ROWS_COOP instances: block b of preprocess_fwd lists its own at big_list[b * PRE_BLOCK ..],
+    // block_big[b] of them (no counter to zero, no atomics); the scan kernel turns the counts into offsets and
+    // sum_big_rows numbers the entries of the frame through the offsets
+    big_list = o;   o = align_up(o + 4 * (size_t)nblocks * PRE_BLOCK, 256);
+    block_big = o;  o = align_up(o + 4 * (size_t)(nblocks + 1), 256);
+    block_big_offs = o; o = align_up(o + 4 * (size_t)(nblocks + 1), 256);
     bytes = o;
   }
 };

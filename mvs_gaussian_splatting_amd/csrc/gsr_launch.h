@@ -6,16 +6,21 @@
 namespace gsr {
 
 // preprocess.hip
-// big_count / big_list: Gaussians with more than ROWS_COOP instances are appended (big_count is zeroed here)
+// block_big / big_list: every block lists its Gaussians with more than ROWS_COOP instances at big_list[block * PRE_BLOCK ..]
+// and writes how many (no counter to zero in front of the frame, no atomics); the scan launch below turns the counts
+// into offsets
 void launch_preprocess_fwd(const GsrParams& p, GeomRec* rec, BinInfo* bin, uint32_t* block_sums, uint32_t* block_vis,
-                           int32_t* radii, uint32_t* big_count, uint32_t* big_list, uint2* block_range, hipStream_t s);
-// folds the gradient rows of every listed Gaussian into its first row (wave-cooperative, fixed order)
-void launch_sum_big_rows(const uint32_t* big_count, const uint32_t* big_list, const GeomRec* rec,
-                         const uint32_t* slot_base, GradRow* rows, uint8_t* row_flags, hipStream_t s);
-// exclusive scans of up to two per-block arrays in one launch (block 0: a, block 1: b); total_x = grand total
+                           int32_t* radii, uint32_t* block_big, uint32_t* big_list, uint2* block_range, hipStream_t s);
+// folds the gradient rows of every listed Gaussian into its first row (wave-cooperative, fixed order); nb = blocks of
+// preprocess_fwd, big_offs = the scanned block_big (nb + 1 entries)
+void launch_sum_big_rows(const uint32_t* big_count, const uint32_t* big_offs, int nb, const uint32_t* big_list,
+                         const GeomRec* rec, const uint32_t* slot_base, GradRow* rows, uint8_t* row_flags, hipStream_t s);
+// exclusive scans of up to three per-block arrays in one launch (block 0: a, block 1: b, block 3: c; block 2 folds
+// block_range, and c comes only with it); total_x = grand total
 void launch_scan_block_sums(const uint32_t* sums_a, uint32_t* offs_a, uint32_t* total_a, const uint32_t* sums_b,
                             uint32_t* offs_b, uint32_t* total_b, int nb, hipStream_t s,
-                            uint32_t* host_mirror = nullptr, const uint2* block_range = nullptr);
+                            uint32_t* host_mirror = nullptr, const uint2* block_range = nullptr,
+                            const uint32_t* sums_c = nullptr, uint32_t* offs_c = nullptr, uint32_t* total_c = nullptr);
 void launch_preprocess_bwd(const GsrParams& p, const int32_t* radii, const GeomRec* rec, const uint32_t* slot_base,
                            const GradRow* rows,
                            const uint8_t* row_flags, const GsrGrads& g, hipStream_t s);

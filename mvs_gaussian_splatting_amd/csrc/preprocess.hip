@@ -216,9 +216,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
                                                                    uint32_t* __restrict__ block_sums,
                                                                    uint32_t* __restrict__ block_vis,
                                                                    int32_t* __restrict__ radii,
-                                                                   uint32_t* __restrict__ big_count,
+                                                                   uint32_t* __restrict__ block_big,
                                                                    uint32_t* __restrict__ big_list,
                                                                    uint2* __restrict__ block_range) {
+  __shared__ uint32_t wave_big[PRE_BLOCK / WAVE];
   __shared__ uint32_t wave_sums[PRE_BLOCK / WAVE];
   __shared__ uint32_t wave_vis[PRE_BLOCK / WAVE];
   __shared__ uint2 wave_range[PRE_BLOCK / WAVE];
@@ -406,8 +407,6 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
     bi.mask = g.tile_mask;
     g.rect_min |= flags << 29;         // the binning copy (bi) stays clean
     rec[idx] = g;
-    // large splats are rare: their gradient rows are pre-summed cooperatively by the backward (sum_big_rows_kernel)
-    if (tiles > ROWS_COOP) big_list[atomicAdd(big_count, 1u)] = (uint32_t)idx;
   }
   if (idx < p.P) {
     radii[idx] = radius;
@@ -428,9 +427,26 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_fwd_kernel(GsrParams p, 
   // block total of tiles_touched -> first level of the hierarchical scan (§8 a5)
   const uint32_t ws = wave_reduce_add_u32(tiles);
   const uint32_t wv = (uint32_t)__popcll(__ballot(tiles != 0u));   // Gaussians that enter the binning
-  if (lane == 0) { wave_sums[wid] = ws; wave_vis[wid] = wv; wave_range[wid] = make_uint2(dinv, dmax); }
+  // Large splats are rare: their gradient rows are pre-summed cooperatively by the backward (sum_big_rows_kernel), which
+  // finds them in this block's stretch of big_list.  (One frame-wide list behind an atomic counter needed a memset node in
+  // front of every frame, and on a scene with 40 k such splats the same-address atomics cost this kernel 85 us.)
+  const bool big = tiles > ROWS_COOP;
+  const unsigned long long big_lanes = __ballot(big);
+  if (lane == 0) {
+    wave_sums[wid] = ws; wave_vis[wid] = wv; wave_range[wid] = make_uint2(dinv, dmax);
+    wave_big[wid] = (uint32_t)__popcll(big_lanes);
+  }
   __syncthreads();
+  if (big) {
+    uint32_t k = (uint32_t)__popcll(big_lanes & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wid; ++w) k += wave_big[w];
+    big_list[(size_t)blockIdx.x * PRE_BLOCK + k] = (uint32_t)idx;
+  }
   if (threadIdx.x == 0) {
+    uint32_t nbig = 0;
+#pragma unroll
+    for (int w = 0; w < PRE_BLOCK / WAVE; ++w) nbig += wave_big[w];
+    block_big[blockIdx.x] = nbig;
     uint32_t s = 0, v = 0;
     uint2 r = make_uint2(0u, 0u);
 #pragma unroll
@@ -454,7 +470,10 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t* _
                                                                 uint32_t* __restrict__ offs_b,
                                                                 uint32_t* __restrict__ total_b, int nb,
                                                                 uint32_t* __restrict__ host_mirror,
-                                                                const uint2* __restrict__ block_range) {
+                                                                const uint2* __restrict__ block_range,
+                                                                const uint32_t* __restrict__ sums_c,
+                                                                uint32_t* __restrict__ offs_c,
+                                                                uint32_t* __restrict__ total_c) {
   constexpr int PER = 32;
   __shared__ uint32_t wave_tot[1024 / WAVE];
   __shared__ uint2 wave_range[1024 / WAVE];
@@ -482,9 +501,9 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t* _
     }
     return;
   }
-  const uint32_t* __restrict__ block_sums = blockIdx.x == 0 ? sums_a : sums_b;
-  uint32_t* __restrict__ block_offs = blockIdx.x == 0 ? offs_a : offs_b;
-  uint32_t* __restrict__ total = blockIdx.x == 0 ? total_a : total_b;
+  const uint32_t* __restrict__ block_sums = blockIdx.x == 0 ? sums_a : blockIdx.x == 1 ? sums_b : sums_c;
+  uint32_t* __restrict__ block_offs = blockIdx.x == 0 ? offs_a : blockIdx.x == 1 ? offs_b : offs_c;
+  uint32_t* __restrict__ total = blockIdx.x == 0 ? total_a : blockIdx.x == 1 ? total_b : total_c;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
   uint32_t carry = 0;
   for (int base = 0; base < nb; base += 1024 * PER) {
@@ -539,7 +558,7 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t* _
   if (tid == 0) {
     block_offs[nb] = carry;
     *total = carry;
-    if (host_mirror) host_mirror[blockIdx.x] = carry;   // pinned host memory: visible once the kernel has completed
+    if (host_mirror && blockIdx.x < 2) host_mirror[blockIdx.x] = carry;   // pinned host memory: visible once the kernel has completed
   }
 }
 
@@ -1010,23 +1029,28 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_bwd_kernel(GsrParams p, 
 
 
 void launch_preprocess_fwd(const GsrParams& p, GeomRec* rec, BinInfo* bin, uint32_t* block_sums, uint32_t* block_vis,
-                           int32_t* radii, uint32_t* big_count, uint32_t* big_list, uint2* block_range, hipStream_t s) {
-  (void)hipMemsetAsync(big_count, 0, 4, s);
+                           int32_t* radii, uint32_t* block_big, uint32_t* big_list, uint2* block_range, hipStream_t s) {
   const int nb = (p.P + PRE_BLOCK - 1) / PRE_BLOCK;
   if (nb > 0)
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(PRE_BLOCK), 0, s, p, rec, bin, block_sums, block_vis, radii,
-                       big_count, big_list, block_range);
+                       block_big, big_list, block_range);
 }
 void launch_scan_block_sums(const uint32_t* sums_a, uint32_t* offs_a, uint32_t* total_a, const uint32_t* sums_b,
                             uint32_t* offs_b, uint32_t* total_b, int nb, hipStream_t s, uint32_t* host_mirror,
-                            const uint2* block_range) {
-  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(block_range ? 3 : (sums_b ? 2 : 1)), dim3(1024), 0, s, sums_a, offs_a, total_a,
-                     sums_b, offs_b, total_b, nb, host_mirror, block_range);
+                            const uint2* block_range, const uint32_t* sums_c, uint32_t* offs_c, uint32_t* total_c) {
+  // blocks: 0 = a, 1 = b, 2 = fold of block_range, 3 = c
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(block_range ? (sums_c ? 4 : 3) : (sums_b ? 2 : 1)), dim3(1024), 0, s, sums_a,
+                     offs_a, total_a, sums_b, offs_b, total_b, nb, host_mirror, block_range, sums_c, offs_c, total_c);
 }
-// One wave per listed Gaussian (grid-stride over the list, whose length lives on the device): flags are read 64 at
-// a time -- most are clear, the tiles behind an opaque surface never reach the instance -- flagged rows are summed in
-// a fixed lane / iteration order and the total replaces the first row.
+// One wave per listed Gaussian: flags are read 64 at a time -- most are clear, the tiles behind an opaque surface never
+// reach the instance -- flagged rows are summed in a fixed lane / iteration order and the total replaces the first row.
+// The list is segmented: block b of preprocess_fwd wrote its entries at big_list[b * PRE_BLOCK ..], and entry e of the
+// frame lies in the block with big_offs[b] <= e < big_offs[b + 1] (big_offs: the scanned block counts, nb + 1 entries).
+// Every wave takes a contiguous stretch of entries (balanced whatever the clustering of the big splats in memory),
+// finds the block of its first entry with a 64-way search (three rounds for 23 k blocks) and then walks on: the 64
+// offsets it holds in its lanes answer the following entries until the walk leaves them.
 __global__ __launch_bounds__(256) void sum_big_rows_kernel(const uint32_t* __restrict__ big_count,
+                                                           const uint32_t* __restrict__ big_offs, int nb,
                                                            const uint32_t* __restrict__ big_list,
                                                            const GeomRec* __restrict__ rec,
                                                            const uint32_t* __restrict__ slot_base,
@@ -1034,8 +1058,35 @@ __global__ __launch_bounds__(256) void sum_big_rows_kernel(const uint32_t* __res
   const uint32_t count = *big_count;
   const int lane = threadIdx.x & (WAVE - 1);
   const uint32_t wave = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE, nwaves = gridDim.x * (256 / WAVE);
-  for (uint32_t e = wave; e < count; e += nwaves) {
-    const uint32_t idx = big_list[e];
+  const uint32_t per = (count + nwaves - 1) / nwaves;
+  const uint32_t e0 = wave * per, e1 = min(count, e0 + per);
+  if (e0 >= e1) return;
+  // largest b in [0, nb) with big_offs[b] <= e0: narrow [lo, hi] 64 probes at a time
+  int lo = 0, hi = nb - 1;
+  while (lo < hi) {
+    const int span = hi - lo, step = (span + WAVE - 1) / WAVE;             // probes at lo + step, lo + 2 step, ...
+    const int pos = lo + (lane + 1) * step;
+    const bool le = pos <= hi && big_offs[pos] <= e0;
+    const int hits = __popcll(__ballot(le));                              // monotone: the first `hits` probes are <= e0
+    const int nlo = lo + hits * step;
+    hi = min(hi, nlo + step - 1);
+    lo = nlo;
+  }
+  int win = lo;                                                           // the lanes hold big_offs[win + 1 + lane],
+  uint32_t win_off = big_offs[win];                                       // win_off = big_offs[win]
+  uint32_t next = win + 1 + lane <= nb ? big_offs[win + 1 + lane] : 0xffffffffu;
+  for (uint32_t e = e0; e < e1; ++e) {
+    // block of e: the first b >= win with big_offs[b + 1] > e
+    unsigned long long m = __ballot(next > e);
+    while (m == 0ull) {
+      win_off = (uint32_t)__shfl((int)next, WAVE - 1, WAVE);              // big_offs[win + 64]: <= e, so inside the array
+      win += WAVE;
+      next = win + 1 + lane <= nb ? big_offs[win + 1 + lane] : 0xffffffffu;
+      m = __ballot(next > e);
+    }
+    const int first = __ffsll((long long)m) - 1, b = win + first;
+    const uint32_t off_b = first == 0 ? win_off : (uint32_t)__shfl((int)next, first - 1, WAVE);   // big_offs[b], from the lanes
+    const uint32_t idx = big_list[(size_t)b * PRE_BLOCK + (e - off_b)];
     const uint2 rr = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(rec + idx) + 48);   // rect_min, rect_wh
     const uint32_t mask = rec[idx].tile_mask;
     const uint32_t n = bin_count(rr.y, mask), slot0 = slot_base[idx];
@@ -1063,9 +1114,11 @@ __global__ __launch_bounds__(256) void sum_big_rows_kernel(const uint32_t* __res
   }
 }
 
-void launch_sum_big_rows(const uint32_t* big_count, const uint32_t* big_list, const GeomRec* rec,
-                         const uint32_t* slot_base, GradRow* rows, uint8_t* row_flags, hipStream_t s) {
-  hipLaunchKernelGGL(sum_big_rows_kernel, dim3(512), dim3(256), 0, s, big_count, big_list, rec, slot_base, rows, row_flags);
+void launch_sum_big_rows(const uint32_t* big_count, const uint32_t* big_offs, int nb, const uint32_t* big_list,
+                         const GeomRec* rec, const uint32_t* slot_base, GradRow* rows, uint8_t* row_flags, hipStream_t s) {
+  if (nb > 0)
+    hipLaunchKernelGGL(sum_big_rows_kernel, dim3(512), dim3(256), 0, s, big_count, big_offs, nb, big_list, rec, slot_base, rows,
+                       row_flags);
 }
 void launch_preprocess_bwd(const GsrParams& p, const int32_t* radii, const GeomRec* rec, const uint32_t* slot_base,
                            const GradRow* rows, const uint8_t* row_flags, const GsrGrads& g, hipStream_t s) {
