@@ -1114,10 +1114,13 @@ __global__ __launch_bounds__(256) void sum_big_rows_kernel(const uint32_t* __res
   }
 }
 
+#ifndef SUM_BIG_BLOCKS
+#define SUM_BIG_BLOCKS 1024   // an entry is a chain of five dependent trips to memory: 4096 waves (heavy-tailed C4 -20 us against 512 blocks; 2048 blocks: -30 us there but +10 us on a frame without big splats)
+#endif
 void launch_sum_big_rows(const uint32_t* big_count, const uint32_t* big_offs, int nb, const uint32_t* big_list,
                          const GeomRec* rec, const uint32_t* slot_base, GradRow* rows, uint8_t* row_flags, hipStream_t s) {
   if (nb > 0)
-    hipLaunchKernelGGL(sum_big_rows_kernel, dim3(512), dim3(256), 0, s, big_count, big_offs, nb, big_list, rec, slot_base, rows,
+    hipLaunchKernelGGL(sum_big_rows_kernel, dim3(SUM_BIG_BLOCKS), dim3(256), 0, s, big_count, big_offs, nb, big_list, rec, slot_base, rows,
                        row_flags);
 }
 void launch_preprocess_bwd(const GsrParams& p, const int32_t* radii, const GeomRec* rec, const uint32_t* slot_base,
