@@ -902,11 +902,14 @@ static void sort_pass(const KeyT* kin, const ValT* vin, KeyT* kout, ValT* vout, 
 // Digit widths of the passes.  A block scatters 4096 items: with 2^w digits a digit's run leaves the block as
 // 4096/2^w contiguous items, so narrow digits write long segments (w = 9: 32-byte fragments; w = 6..8: 64..256 bytes)
 // and need fewer ballots to rank.  The pass count is ceil(end_bit / 9) (the fewest the 9-bit kernels allow); the bits
-// are spread evenly over those passes: 32 depth bits -> 8+8+8+8, 13 tile bits -> 7+6, 45-bit keys -> 9 x 5.
+// are spread evenly over those passes, the wider digits LAST: 32 depth bits -> 8+8+8+8, 13 tile bits -> 6+7, 45-bit keys ->
+// 9 x 5.  (The last pass of the tile sort sees the top bits of the tile id, which a scene with dense blobs concentrates on
+// a few values: its LDS histogram atomics collide less over 128 bins than over 64 -- heavy-tailed C4 tile sort -19 us,
+// uniform clouds unchanged.)
 int sort_pass_plan(int end_bit, int widths[8]) {
   const int passes = sort_passes(end_bit);
   const int lo = end_bit / passes, extra = end_bit % passes;
-  for (int p = 0; p < passes; ++p) widths[p] = lo + (p < extra ? 1 : 0);
+  for (int p = 0; p < passes; ++p) widths[p] = lo + (p >= passes - extra ? 1 : 0);
   return passes;
 }
 
