@@ -4,7 +4,9 @@ upstream-like footprints: per-stage times, instance counts, lis
 take the rare paths (more than 64 gradient rows, rects beyond the packed sort payload), whether the depth sort's fourth
 pass ran, and the forward without the count read-back.
 
-    PYTHONPATH=.:tools python tools/bench_heavy_tail.py [P] [iters] [log footprint mean]
+    PYTHONPATH=.:tools python tools/bench_heavy_tail.py [P] [iters] [log footprint mean] [--morton]
+
+--morton: the same cloud stored along a Morton curve (mvs_gaussian_splatting_amd/layout.py).
 """
 import ctypes as C
 import math
@@ -17,14 +19,18 @@ from mvs_gaussian_splatting_amd import _lib
 from mvs_gaussian_splatting_amd.synthetic import make_heavy_tail_model
 from scene_gpu import GpuScene
 
-P = int(sys.argv[1]) if len(sys.argv) > 1 else 6_000_000
-iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-lfm = float(sys.argv[3]) if len(sys.argv) > 3 else math.log(0.0013)
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+P = int(argv[0]) if len(argv) > 0 else 6_000_000
+iters = int(argv[1]) if len(argv) > 1 else 10
+lfm = float(argv[2]) if len(argv) > 2 else math.log(0.0013)
 
 
 def mutate(model):
     ht = make_heavy_tail_model(model._xyz.shape[0], model.max_sh_degree, seed=3, log_footprint_mean=lfm)
     model._xyz, model._scaling, model._opacity = ht._xyz, ht._scaling, ht._opacity
+    if "--morton" in sys.argv:
+        from mvs_gaussian_splatting_amd.layout import reorder_gaussians_
+        reorder_gaussians_(model)
 
 
 s = GpuScene("C4", P=P, mutate=mutate, fused=True)
