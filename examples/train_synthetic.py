@@ -50,7 +50,10 @@ def make_problem(dev, P=4000, W=256, H=160, n_views=8, seed=0):
     return targets, cams, bg, pipe, model
 
 
-def train(dev, iterations=60, densification_interval=20, densify_from_iter=10, extent=2.0, grad_threshold=0.0006, log=None):
+def train(dev, iterations=60, densification_interval=20, densify_from_iter=10, extent=2.0, grad_threshold=0.0006, log=None,
+          spatial_order=False):
+    """spatial_order: after every densification the cloud (and the Adam moments) is stored along a Morton curve
+    (mvs_gaussian_splatting_amd/layout.py) instead of the reference's [kept | clones | children] order."""
     targets, cams, bg, pipe, model = make_problem(dev)
     history, sizes = [], []
     for it in range(1, iterations + 1):
@@ -63,7 +66,7 @@ def train(dev, iterations=60, densification_interval=20, densify_from_iter=10, e
             model.optimizer.step()
             model.optimizer.zero_grad(set_to_none=True)
             if it > densify_from_iter and it % densification_interval == 0:
-                info = densify_and_prune(model, grad_threshold, 0.005, extent, 20)
+                info = densify_and_prune(model, grad_threshold, 0.005, extent, 20, spatial_order=spatial_order)
                 sizes.append(info["points"])
                 if log:
                     log(f"  iteration {it}: densify_and_prune -> {info}")

@@ -11,14 +11,21 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "examples"))
 
 
-def test_training_loop_converges_and_state_stays_consistent(tmp_path):
+@pytest.mark.parametrize("spatial_order", [False, True])
+def test_training_loop_converges_and_state_stays_consistent(tmp_path, spatial_order):
+    """spatial_order: every densification also stores the cloud and the Adam moments along a Morton curve (layout.py)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from train_synthetic import train
     from mvs_gaussian_splatting_amd.densify import GROUP_ATTR
     from mvs_gaussian_splatting_amd.ply_io import save_ply, load_ply
     dev = torch.device("cuda:0")
-    model, history, sizes = train(dev, iterations=100, densification_interval=20, densify_from_iter=10)
+    model, history, sizes = train(dev, iterations=100, densification_interval=20, densify_from_iter=10,
+                                  spatial_order=spatial_order)
+    if spatial_order:
+        from mvs_gaussian_splatting_amd.layout import morton_permutation
+        perm = morton_permutation(model._xyz)      # positions moved since the last densification: mostly, not exactly, sorted
+        assert float((perm[1:] > perm[:-1]).float().mean()) > 0.9
     first, last = sum(history[:8]) / 8, sum(history[-8:]) / 8
     assert all(h == h for h in history) and last < 0.7 * first, (first, last)
     assert len(sizes) == 5 and all(s > 0 for s in sizes) and sizes[-1] > 4000        # the cloud grew
