@@ -368,7 +368,8 @@ def last_counts(dev, P: int, W: int, H: int) -> tuple:
 
 
 def reissued_frames(dev, P: int, W: int, H: int) -> int:
-    """Frames of that shape that did not fit their capacity and were issued a second time (verified mode)."""
+    """Frames of that shape that were issued a second time (verified mode): they did not fit their capacity, or spanned
+    2^24 depth-key steps after being issued without the depth sort's fourth pass."""
     key = (torch.device(dev).index or 0, int(P), int(W), int(H), _binning_mode_value)
     with _defer_lock:
         st = _states.get(key)
