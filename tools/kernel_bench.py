@@ -88,3 +88,18 @@ if "--wide-depth" not in sys.argv:
     torch.cuda.synchronize()
     s.params.depth_span_lt24 = 0
     print(f"sync-free forward, depth_span_lt24: {t0.elapsed_time(t1) / iters:.3f} ms per frame on the device")
+    # ... with the counts event recorded behind the scan kernel (what the verified mode adds on the device side)
+    import ctypes
+    ev = ctypes.c_void_p()
+    _lib.check(s.lib.gsr_event_create(ctypes.byref(ev)), "event_create")
+    s.params.depth_span_lt24 = 1
+    s.forward_sync_free(event=ev)
+    torch.cuda.synchronize()
+    t0.record()
+    for _ in range(iters):
+        s.forward_sync_free(event=ev)
+    t1.record()
+    torch.cuda.synchronize()
+    s.params.depth_span_lt24 = 0
+    print(f"sync-free forward, depth_span_lt24, counts event recorded: {t0.elapsed_time(t1) / iters:.3f} ms per frame on the device")
+    _lib.check(s.lib.gsr_event_destroy(ev), "event_destroy")

@@ -61,8 +61,9 @@ class GpuScene:
                                           self.binning.numel(), self.img.data_ptr(), self.R, self.V, self.color.data_ptr(),
                                           self.stream), "render")
 
-    def forward_sync_free(self, capacity=None):
-        """gsr_forward with a caller-side capacity (default 1.5 x the last two-call frame's count)."""
+    def forward_sync_free(self, capacity=None, event=None):
+        """gsr_forward with a caller-side capacity (default 1.5 x the last two-call frame's count); event: a handle from
+        gsr_event_create recorded behind the scan kernel, as the operator's verified mode does."""
         lib = self.lib
         cap = int(capacity or (self.cap if hasattr(self, "cap") else int(self.R * 1.5)))
         self.cap = cap
@@ -70,7 +71,7 @@ class GpuScene:
         if self.binning is None or self.binning.numel() < nb:
             self.binning = torch.empty(nb, dtype=torch.uint8, device=self.dev)
         _lib.check(lib.gsr_forward(C.byref(self.params), self.geom.data_ptr(), self.binning.data_ptr(), self.binning.numel(),
-                                   cap, self.img.data_ptr(), self.radii.data_ptr(), self.color.data_ptr(), None,
+                                   cap, self.img.data_ptr(), self.radii.data_ptr(), self.color.data_ptr(), event,
                                    self.stream), "gsr_forward")
         self.R, self.V = cap, self.P      # what the workspaces are laid out for (gsr_backward takes these)
 
