@@ -39,9 +39,10 @@ def test_struct_layouts_match_the_c_compiler():
 #include <stddef.h>
 #include "gsr.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %d %zu %zu %d\n", sizeof(GsrParams), sizeof(GsrGrads), offsetof(GsrParams, means3D),
+  printf("%zu %zu %zu %zu %zu %zu %d %zu %zu %d %zu %zu\n", sizeof(GsrParams), sizeof(GsrGrads), offsetof(GsrParams, means3D),
          offsetof(GsrParams, bg), offsetof(GsrParams, counts_pinned), offsetof(GsrGrads, dL_dshs_rest), GSR_STAGE_COUNT,
-         offsetof(GsrParams, debug_flags), offsetof(GsrGrads, stats_max_radii2D), GSR_ABI_VERSION);
+         offsetof(GsrParams, debug_flags), offsetof(GsrGrads, stats_max_radii2D), GSR_ABI_VERSION,
+         offsetof(GsrParams, visible_out), offsetof(GsrParams, depth_span_lt24));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -53,7 +54,8 @@ int main(void) {
     vals = list(map(int, out))
     P, G = _lib.GsrParams, _lib.GsrGrads
     assert vals == [C.sizeof(P), C.sizeof(G), P.means3D.offset, P.bg.offset, P.counts_pinned.offset, G.dL_dshs_rest.offset,
-                    _lib.STAGE_COUNT, P.debug_flags.offset, G.stats_max_radii2D.offset, _lib.ABI_VERSION]
+                    _lib.STAGE_COUNT, P.debug_flags.offset, G.stats_max_radii2D.offset, _lib.ABI_VERSION,
+                    P.visible_out.offset, P.depth_span_lt24.offset]
 
 
 def test_workspace_sizes_are_monotone_and_aligned():
