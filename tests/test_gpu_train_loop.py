@@ -44,8 +44,10 @@ def test_training_loop_converges_and_state_stays_consistent(tmp_path, spatial_or
         assert torch.equal(back[k].cpu(), getattr(model, k).detach().cpu()), k
 
 
-def test_offline_render_of_a_saved_ply_matches_the_live_model(tmp_path):
-    """render.py's path: save_ply -> load_ply -> render under no_grad gives the images of the live model bit for bit."""
+@pytest.mark.parametrize("spatial_order", [False, True])
+def test_offline_render_of_a_saved_ply_matches_the_live_model(tmp_path, spatial_order):
+    """render.py's path: save_ply -> load_ply -> render under no_grad gives the images of the live model bit for bit;
+    with the loaded model stored along a Morton curve (the example's default) up to the order of equal-depth ties."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from train_synthetic import make_problem
@@ -57,11 +59,14 @@ def test_offline_render_of_a_saved_ply_matches_the_live_model(tmp_path):
     _, _, bg, pipe, model = make_problem(dev, P=3000)
     path = str(tmp_path / "point_cloud.ply")
     save_ply(model, path)
-    _, images = render_set(path, str(tmp_path / "renders"), n_views=3, width=200, height=120)
+    _, images = render_set(path, str(tmp_path / "renders"), n_views=3, width=200, height=120, spatial_order=spatial_order)
     for v, img in enumerate(images):
         cam = orbit_camera(v, 3, 200, 120, 220.0, 220.0, centre=(0.0, 0.0, 4.0), device=dev)
         with torch.no_grad():
             live = render(cam, model, pipe, bg)["render"]
-        assert torch.equal(img, live)
+        if spatial_order:      # a pair of equal float32 depths in one tile may blend in the other order (layout.py)
+            assert float((img != live).any(dim=0).float().mean()) < 1e-3 and float((img - live).abs().max()) < 5e-3
+        else:
+            assert torch.equal(img, live)
         data = open(tmp_path / "renders" / f"{v:05d}.ppm", "rb").read()
         assert data.startswith(b"P6\n200 120\n255\n") and len(data) == 15 + 200 * 120 * 3
