@@ -7,6 +7,11 @@ synthetic Gaussians, one view per GPU (weak scaling by independent views; the on
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+Both forms work for N > 1.  Without a torchrun environment (WORLD_SIZE unset) `python bench.py --gpus N` is the LAUNCHER:
+it starts `python -m torch.distributed.run ... bench.py <same arguments>` as a child process -- before anything in this
+process has touched the GPU --, hands rank 0's single JSON line on to its own stdout and exits with the children's
+worst exit code (`launch_ranks`).
+
 Two HEADLINE regions, each EXACTLY K steps bracketed by barrier + torch.cuda.synchronize() and reduced with
 MAX over ranks:  (A) forward-only render under no_grad  -> `value` (Mpixels/s, whole job);
                  (B) train step = render + L1 + backward + densification stats (+ loss all-reduce)
@@ -228,6 +233,129 @@ def c5_summary(per_rank_fwd_s, per_rank_train_s, rounds, world, W, H, n_views=8)
             "per_rank_train_ms_per_view": [round(t / rounds / max(v, 1) * 1e3, 3) for t, v in zip(per_rank_train_s, per_rank_views)]}
 
 
+def visible_gpus():
+    """Devices this process would see.  torch.cuda.device_count() reads the count without creating a HIP context on this
+    image (torch.cuda.is_available() would: never call that in the launcher)."""
+    try:
+        return int(torch.cuda.device_count())
+    except Exception:  # noqa: BLE001
+        return 0
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def pick_result_line(stdout_text):
+    """The one result line among whatever the rank processes wrote to stdout: the LAST line that parses as a JSON object
+    with a "metric" key (rank 0 prints exactly one; banners of native libraries are not JSON)."""
+    found = None
+    for ln in stdout_text.splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                if "metric" in json.loads(ln):
+                    found = ln
+            except ValueError:
+                pass
+    return found
+
+
+def launch_ranks(n, argv, script=None, out=None, env=None, timeout=None, gpus_visible=None):
+    """`python bench.py --gpus N` without a torchrun environment: start N fresh rank processes and relay rank 0's line.
+
+    The parent must not have initialised the GPU (it has only imported torch): the ranks are CHILD processes of
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` --
+    nothing is exec'ed over a process that holds a HIP context.  Returns the exit code: the launcher's (non-zero when any
+    rank failed: torchrun tears the others down), or 1 when every rank exited 0 but no result line arrived.
+    With fewer visible devices than ranks (a one-card rehearsal) the ranks share cuda:0 (GSR_BENCH_SHARE_GPU=1): RCCL
+    refuses a duplicate device, the ranks agree on gloo for the loss all-reduce, and the line says "valid": false.
+    `script` / `out` / `env` / `gpus_visible` are injectable for the CPU test (tests/test_bench_protocol.py)."""
+    import subprocess
+    script = script or os.path.abspath(__file__)
+    out = out if out is not None else sys.stdout
+    env = dict(os.environ if env is None else env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK"):
+        env.pop(k, None)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL's peer mappings need it on this pool
+    have = visible_gpus() if gpus_visible is None else int(gpus_visible)
+    if have < n and env.get("GSR_BENCH_SHARE_GPU") != "1":
+        print(f"[bench] launcher: {have} device(s) visible for {n} ranks -- REHEARSAL: the ranks share cuda:0 "
+              "(GSR_BENCH_SHARE_GPU=1), RCCL cannot form a communicator over one device, the line will say valid: false",
+              file=sys.stderr, flush=True)
+        env["GSR_BENCH_SHARE_GPU"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
+    print("[bench] launcher: " + " ".join(cmd), file=sys.stderr, flush=True)
+    try:
+        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, timeout=timeout)
+    except subprocess.TimeoutExpired as ex:
+        print(f"[bench] launcher: ranks did not finish within {timeout} s", file=sys.stderr, flush=True)
+        if ex.stdout:
+            sys.stderr.write(ex.stdout.decode(errors="replace"))
+        return 124
+    text = proc.stdout.decode(errors="replace")
+    line = pick_result_line(text)
+    for ln in text.splitlines():                                # whatever else reached stdout goes to stderr
+        if ln.strip() and ln.strip() != line:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0:
+        print(f"[bench] launcher: rank processes failed (exit code {proc.returncode})", file=sys.stderr, flush=True)
+        return proc.returncode if 0 < proc.returncode < 256 else 1
+    if line is None:
+        print("[bench] launcher: every rank exited 0 but rank 0 printed no result line", file=sys.stderr, flush=True)
+        return 1
+    out.write(line + "\n")
+    out.flush()
+    return 0
+
+
+def rccl_single_rank_probe(timeout=120):
+    """RCCL exercised on whatever this box has: a ONE-rank communicator (backend "nccl") in a fresh child process does the
+    path's collective -- all_reduce(SUM) of the 4-float loss vector -- 200 times on cuda:0.  Says that librccl loads, a
+    communicator comes up and its kernel runs on gfx950, and what one such collective costs to issue; it says nothing about
+    xGMI (there is no peer).  Child process: a hung communicator costs the timeout, not the bench."""
+    import subprocess
+    code = (
+        "import os, json, time, torch, torch.distributed as dist\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')\n"
+        "dev = torch.device('cuda', 0); torch.cuda.set_device(dev)\n"
+        "dist.init_process_group(backend='nccl', device_id=dev)\n"
+        "v = torch.tensor([0.25, 0.25, 1.0, 0.0], device=dev)\n"
+        "for _ in range(20): dist.all_reduce(v)\n"
+        "torch.cuda.synchronize(dev); t0 = time.perf_counter()\n"
+        "for _ in range(200): dist.all_reduce(v)\n"
+        "torch.cuda.synchronize(dev); dt = (time.perf_counter() - t0) / 200\n"
+        "ok = bool(torch.equal(v.cpu(), torch.tensor([0.25, 0.25, 1.0, 0.0])))\n"
+        "ver = '.'.join(str(x) for x in torch.cuda.nccl.version())\n"
+        "print(json.dumps({'ok': ok, 'ranks': dist.get_world_size(), 'backend': dist.get_backend(), 'rccl_version': ver, "
+        "'allreduce_16B_us': round(dt * 1e6, 2)}))\n"
+        "dist.destroy_process_group()\n")
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    env["MASTER_PORT"] = str(free_port())
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"ok": False, "why": f"no answer within {timeout} s"}
+    for ln in reversed(r.stdout.decode(errors="replace").splitlines()):
+        if ln.startswith("{"):
+            try:
+                d = json.loads(ln)
+                d["what"] = "one-rank RCCL communicator on cuda:0: all_reduce(SUM) of the 4-float loss vector, 200 calls"
+                return d
+            except ValueError:
+                pass
+    return {"ok": False, "why": (r.stderr.decode(errors="replace").strip().splitlines() or ["no output"])[-1][:300],
+            "returncode": r.returncode}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,7 +374,15 @@ def main():
                     help="only the two headline regions + the stage-timer pass (what the rocprofv3 passes run: every launch "
                          "of a kernel then belongs to the headline view)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-rccl-probe", action="store_true", help="skip the one-rank RCCL communicator probe (N = 1 only)")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # the plain command form: this process becomes the launcher of N rank processes (it has not touched the GPU)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    rccl_probe = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.headline_only and not args.no_rccl_probe:
+        # a child process, started BEFORE this process creates its HIP context (a process that holds the GPU starts nothing)
+        rccl_probe = rccl_single_rank_probe()
     # stdout carries exactly one line, the JSON result: native libraries (the RCCL / gloo banners) write to fd 1 too,
     # so fd 1 is pointed at stderr for the run and the result goes to a duplicate of the original stdout
     sys.stdout.flush()
@@ -261,8 +397,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}: launch as `python bench.py --gpus N` or as "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
     # one process per GPU; GSR_BENCH_SHARE_GPU=1 (rehearsal on a 1-GPU box, gloo backend) lets ranks share cuda:0
@@ -720,6 +856,8 @@ def main():
             line.update(unfused)
         if layout:
             line.update(layout)
+        if rccl_probe is not None:
+            line["rccl_single_rank_probe"] = rccl_probe
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(cfg, args.seed)

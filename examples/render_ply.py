@@ -3,9 +3,10 @@ a set of orbit views through the drop-in ``render`` and write them as binary PPM
 
     python examples/render_ply.py point_cloud.ply out_dir [n_views] [width] [height]
 
-A model that is only rendered can be stored in any order: ``render_set(..., spatial_order=True)`` (the default) puts it along a
-Morton curve after loading (``mvs_gaussian_splatting_amd/layout.py``: the same images up to the order of equal-depth ties, the
-frames 5-7 % faster at 6 M Gaussians).
+By default the model is rendered in the order the PLY stores it: the images are then those of the reference's stable
+index-order sort.  ``render_set(..., spatial_order=True)`` (opt-in) puts the loaded model along a Morton curve first
+(``mvs_gaussian_splatting_amd/layout.py``: frames 5-7 % faster at 6 M Gaussians, but equal-depth ties inside a tile may blend
+in the other order -- 279 of 2 M pixels differed by up to 1.2e-3 at 6 M Gaussians).
 """
 import os
 import sys
@@ -45,7 +46,7 @@ def write_ppm(path, image):
 
 
 def render_set(ply_path, out_dir, n_views=8, width=256, height=160, focal=220.0, centre=(0.0, 0.0, 4.0), device="cuda:0",
-               spatial_order=True):
+               spatial_order=False):
     dev = torch.device(device)
     model = PlyModel(ply_path, dev)
     if spatial_order:

@@ -421,7 +421,13 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(uint32_t* __restrict
     }
   } else if (n_dev) {
     const uint32_t n = *n_dev;
-    if (n == 0) return;
+    if (n == 0) {
+      // no item on the device (a frame without a visible Gaussian, or a predicated pass that does not run): the row total
+      // is still published -- the segmented pass and ranges_and_order_from_sort read totals[] whatever the count was, and
+      // would otherwise rebuild the PREVIOUS frame's runs from what that frame left here
+      if (threadIdx.x == 0) totals[blockIdx.x] = 0;
+      return;
+    }
     nblocks = min(nblocks, (n + SORT_TILE - 1) / SORT_TILE);   // columns past the device-side count are never written or read
   }
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;

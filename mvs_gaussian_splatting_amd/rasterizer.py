@@ -483,15 +483,16 @@ def _run_forward(lib, dev, params, P: int, W: int, H: int):
         params.depth_span_lt24 = 0
         R, V = int(words[0]), int(words[1])
         span = _depth_span(words, V)
-        st.observe(R, V, span)
+        with _defer_lock:        # forward calls of several threads may share this (device, P, W, H) state
+            st.observe(R, V, span)
         if R <= cap and not (narrow and span >> _DEPTH_SORT_BITS):
             return color, _Frame(geom, binning, img, radii, cap, P, None, (R, V))
         # The frame did not fit (its kernels dropped the instances past the capacity: no out-of-bounds access), or spans
         # more depth than it was sorted for (lists in the wrong order), and is still running.  Issue it again behind
         # itself, on the two-call path, into the same outputs -- nothing of the wrong frame has left the operator.
-        st.reissued += 1
-        if params.forward_only:
-            with _defer_lock:
+        with _defer_lock:
+            st.reissued += 1
+            if params.forward_only:
                 st.fo_ws.pop(stream, None)
     pinned, _words = _counts_pinned_thread()
     params.counts_pinned = pinned.data_ptr()
@@ -499,7 +500,8 @@ def _run_forward(lib, dev, params, P: int, W: int, H: int):
     _lib.check(lib.gsr_forward_preprocess(C.byref(params), geom.data_ptr(), _ptr(radii), stream,
                                           C.byref(num_rendered), C.byref(num_visible)), "gsr_forward_preprocess")
     R, V = int(num_rendered.value), int(num_visible.value)
-    st.observe(R, V, _depth_span(_words, V))
+    with _defer_lock:
+        st.observe(R, V, _depth_span(_words, V))
     nbytes = lib.gsr_binning_bytes(R, V, W, H, mode)
     binning = torch.empty(_round_ws(nbytes), dtype=torch.uint8, device=dev)
     _lib.check(lib.gsr_forward_render(C.byref(params), geom.data_ptr(), binning.data_ptr(), nbytes, img.data_ptr(),

@@ -153,3 +153,78 @@ def test_issue_roof_model_prices_the_counted_classes_at_their_measured_rates():
     assert m["valu_issue_cycles"] == int(cycles)
     assert m["frac_of_issue_roof"] == round(cycles / (1024 * 2.0e9 * 1e-6), 4)
     assert bench.issue_model({}, 4.0, 1e-6, 2.0e9) is None and bench.issue_model(mix, 4.0, 0.0, 2.0e9) is None
+
+
+# ---- `python bench.py --gpus N` as its own launcher ---------------------------------------------------
+_FAKE_RANK = '''
+import json, os, sys
+import torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["MASTER_ADDR"] == "127.0.0.1"
+mode = sys.argv[sys.argv.index("--mode") + 1] if "--mode" in sys.argv else "ok"
+dist.init_process_group(backend="gloo")
+t = torch.tensor([1.0, float(rank)])
+dist.all_reduce(t)
+print("banner of a native library, rank", rank)           # noise on stdout: must not reach the launcher's stdout
+if mode == "fail" and rank == world - 1:
+    sys.exit(7)
+if rank == 0 and mode != "silent":
+    print(json.dumps({"metric": "fake", "n_gpus": world, "ranks_seen": t[0].item(), "rank_sum": t[1].item(),
+                      "share": os.environ.get("GSR_BENCH_SHARE_GPU"), "argv": sys.argv[1:]}))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _launch(tmp_path, world, mode, gpus_visible):
+    import io
+    import json
+    bench = _bench_module()
+    script = tmp_path / "fake_rank.py"
+    script.write_text(_FAKE_RANK)
+    out = io.StringIO()
+    rc = bench.launch_ranks(world, ["--gpus", str(world), "--mode", mode], script=str(script), out=out, timeout=240,
+                            gpus_visible=gpus_visible)
+    lines = [ln for ln in out.getvalue().splitlines() if ln.strip()]
+    return rc, [json.loads(ln) for ln in lines]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_plain_command_launches_n_fresh_ranks_and_relays_one_line(tmp_path, world):
+    """`python bench.py --gpus N` without WORLD_SIZE: N child processes under torch.distributed.run (gloo here), rank 0's
+    single JSON line on the launcher's stdout and nothing else, exit code 0; the arguments reach every rank unchanged."""
+    rc, lines = _launch(tmp_path, world, "ok", gpus_visible=8)
+    assert rc == 0 and len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == world and d["ranks_seen"] == world and d["rank_sum"] == sum(range(world))
+    assert d["argv"] == ["--gpus", str(world), "--mode", "ok"]
+    assert d["share"] is None                       # enough devices: every rank gets its own
+
+
+def test_launcher_marks_a_one_card_rehearsal_and_reports_failures(tmp_path):
+    rc, lines = _launch(tmp_path, 2, "ok", gpus_visible=1)
+    assert rc == 0 and lines[0]["share"] == "1"     # fewer devices than ranks: the ranks are told to share cuda:0
+    rc, lines = _launch(tmp_path, 2, "fail", gpus_visible=8)
+    assert rc != 0 and lines == []                  # a failed rank: non-zero exit, no result line handed on
+    rc, lines = _launch(tmp_path, 2, "silent", gpus_visible=8)
+    assert rc == 1 and lines == []                  # every rank exited 0 but nobody printed a result
+
+
+def test_result_line_is_picked_among_noise():
+    bench = _bench_module()
+    txt = 'NCCL version 2.x\n{"not": "it"}\n{"metric": "m", "value": 1}\ntrailing banner\n'
+    assert bench.pick_result_line(txt) == '{"metric": "m", "value": 1}'
+    assert bench.pick_result_line("nothing here\n{broken json}\n") is None
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus(monkeypatch):
+    """Under a torchrun environment `--gpus` must equal WORLD_SIZE (the driver passes both); a mismatch is an error, not a
+    silent single-rank run."""
+    import subprocess
+    import sys
+    import os
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--no-rccl-probe"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode != 0 and b"WORLD_SIZE=2 but --gpus 1" in r.stderr

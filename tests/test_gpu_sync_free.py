@@ -339,3 +339,131 @@ def test_full_size_C3_frame_without_readback_equals_the_two_call_frame(gpu_devic
     for k in ("color", "final_T", "n_contrib", "radii"):
         assert torch.equal(out[k], ref[k]), k
     assert np.array_equal(out["point_list"], ref["point_list"]) and np.array_equal(out["ranges"], ref["ranges"])
+
+
+# ---- a frame WITHOUT a single instance, issued into the state an ordinary frame left behind ------------
+def _away_camera(cam, dev):
+    """The camera of ``cam`` turned by 180 degrees about the vertical axis: every Gaussian of the cloud lies behind it."""
+    from mvs_gaussian_splatting_amd.synthetic import SyntheticCamera
+    f = lambda fov, px: px / (2.0 * math.tan(fov * 0.5))  # noqa: E731
+    return SyntheticCamera(cam.image_width, cam.image_height, f(cam.FoVx, cam.image_width), f(cam.FoVy, cam.image_height),
+                           R=np.diag([-1.0, 1.0, -1.0]), T=np.zeros(3), device=dev)
+
+
+# 352 x 208 = 286 tiles: the tile sort is one pass (ranges = scan of its digit totals); 640 x 400 = 1000 tiles: two passes,
+# the last one segmented by the first one's totals
+@pytest.mark.parametrize("size", [(352, 208), (640, 400)])
+@pytest.mark.parametrize("mode", ["verified", "deferred"])
+def test_a_frame_without_instances_after_an_ordinary_one_is_the_background(gpu_device, fresh_state, size, mode):
+    """The capacity (and every workspace word) is left by an ordinary view; the next view sees nothing.  The sort's row
+    scan has no item to count -- its totals, the segment table of the second pass and the tile ranges must say so instead
+    of repeating the frame before: image == background, every range (0, 0), every gradient zero."""
+    rz = fresh_state
+    rz.set_sync_free(mode)
+    W, H = size
+    model, cam, _, target = small_scene(P=6000, sh_degree=2, width=W, height=H, scale=0.03)
+    model.to(gpu_device); cam.to(gpu_device)
+    target = target.to(gpu_device)
+    for p in model.parameters():
+        p.requires_grad_(True)
+    bg = torch.tensor([0.25, 0.5, 0.75], device=gpu_device)
+    away = _away_camera(cam, gpu_device)
+    pkg0, _ = _step(model, cam, bg, target)                       # learns the capacity
+    assert rz.frame_counts(pkg0["render"])[0] > 1000
+    _step(model, cam, bg, target)                                 # gsr_forward: leaves its totals in the workspaces
+    for rep in range(2):
+        pkg, g = _step(model, away, bg, target)
+        assert rz.frame_counts(pkg["render"]) == (0, 0)
+        assert torch.equal(pkg["render"], bg[:, None, None].expand(3, H, W))
+        assert not pkg["visibility_filter"].any() and not pkg["radii"].any()
+        for t in g:
+            assert not t.any()
+    pkg1, _ = _step(model, cam, bg, target)                       # and the ordinary view is itself again
+    assert torch.equal(pkg1["render"], pkg0["render"])
+    with torch.no_grad():                                         # forward-only frames share their workspaces outright
+        from mvs_gaussian_splatting_amd import render
+        from mvs_gaussian_splatting_amd.synthetic import PipelineParams
+        a = render(cam, model, PipelineParams(), bg)["render"]
+        b = render(away, model, PipelineParams(), bg)["render"]
+        c = render(cam, model, PipelineParams(), bg)["render"]
+    rz.synchronize_counts()
+    assert torch.equal(a, pkg0["render"].detach()) and torch.equal(c, a)
+    assert torch.equal(b, bg[:, None, None].expand(3, H, W))
+
+
+@pytest.mark.parametrize("size", [(352, 208), (640, 400)])
+def test_raw_gsr_forward_without_instances_into_used_workspaces(gpu_device, size):
+    """The same through the raw C ABI: two ``gsr_forward`` calls into ONE set of workspaces, the second with every
+    Gaussian behind the camera: ranges all (0, 0), image == background, counts 0."""
+    from gpu_util import product_settings
+    from mvs_gaussian_splatting_amd import _lib
+    from mvs_gaussian_splatting_amd.rasterizer import _make_params
+    lib = _lib.load()
+    dev = gpu_device
+    W, H = size
+    model, cam, _, _ = small_scene(P=6000, sh_degree=1, width=W, height=H, scale=0.03)
+    model.to(dev)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    P = 6000
+    e = torch.empty(0, device=dev)
+    cap = 1 << 18
+    with torch.cuda.device(dev), torch.no_grad():
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        geom = torch.empty(lib.gsr_geom_bytes(P), dtype=torch.uint8, device=dev)
+        img = torch.empty(lib.gsr_image_bytes(W, H), dtype=torch.uint8, device=dev)
+        nb = lib.gsr_binning_bytes(cap, P, W, H, _lib.BINNING_TWO_LEVEL_CULLED)
+        binning = torch.empty(nb, dtype=torch.uint8, device=dev)
+        radii = torch.zeros(P, dtype=torch.int32, device=dev)
+        color = torch.empty(3, H, W, device=dev)
+        pinned = torch.zeros(16, dtype=torch.int32).pin_memory()
+        gx, gy = (W + 15) // 16, (H + 15) // 16
+        results = []
+        for c in (cam, _away_camera(cam, dev), cam, _away_camera(cam, dev)):
+            st = product_settings(c, bg, 1, dev)
+            params, keep = _make_params(dev, st, model.get_xyz.contiguous(), model.get_features.contiguous(), e,
+                                        model.get_opacity.contiguous(), model.get_scaling.contiguous(),
+                                        model.get_rotation.contiguous(), e)
+            params.binning_mode = _lib.BINNING_TWO_LEVEL_CULLED
+            params.counts_pinned = pinned.data_ptr()
+            _lib.check(lib.gsr_forward(C.byref(params), geom.data_ptr(), binning.data_ptr(), nb, cap, img.data_ptr(),
+                                       radii.data_ptr(), color.data_ptr(), None, stream), "gsr_forward")
+            final_T = torch.empty(H, W, device=dev)
+            n_contrib = torch.empty(H, W, dtype=torch.int32, device=dev)
+            ranges = torch.empty(gx * gy, 2, dtype=torch.int32, device=dev)
+            _lib.check(lib.gsr_debug_read_image(img.data_ptr(), W, H, final_T.data_ptr(), n_contrib.data_ptr(),
+                                                ranges.data_ptr(), stream), "read_img")
+            torch.cuda.synchronize(dev)
+            results.append((int(pinned[0]), int(pinned[1]), color.clone(), ranges.clone(), final_T.clone(), n_contrib.clone()))
+            del keep
+    assert results[0][0] > 1000 and results[0][0] <= cap
+    for k in (1, 3):
+        R, V, col, ranges, final_T, n_contrib = results[k]
+        assert (R, V) == (0, 0)
+        assert not ranges.any()
+        assert torch.equal(col, bg[:, None, None].expand(3, H, W))
+        assert torch.equal(final_T, torch.ones_like(final_T)) and not n_contrib.any()
+    assert torch.equal(results[2][2], results[0][2]) and torch.equal(results[2][3], results[0][3])
+
+
+@pytest.mark.parametrize("size", [(352, 208), (640, 400)])
+def test_graphed_renderer_frame_without_instances(gpu_device, size):
+    from mvs_gaussian_splatting_amd import render
+    from mvs_gaussian_splatting_amd.graphed import GraphedRenderer
+    from mvs_gaussian_splatting_amd.synthetic import PipelineParams
+    dev = gpu_device
+    W, H = size
+    model, cam, _, _ = small_scene(P=6000, sh_degree=2, width=W, height=H, scale=0.03)
+    model.to(dev); cam.to(dev)
+    bg = torch.tensor([0.3, 0.1, 0.6], device=dev)
+    away = _away_camera(cam, dev)
+    gr = GraphedRenderer(model, PipelineParams(), bg)
+    with torch.no_grad():
+        want = render(cam, model, PipelineParams(), bg)["render"]
+        for c, expect in ((cam, want), (cam, want), (away, None), (away, None), (cam, want)):
+            got = gr.render(c)
+            if expect is None:
+                assert torch.equal(got["render"], bg[:, None, None].expand(3, H, W))
+                assert not got["radii"].any() and not got["visibility_filter"].any()
+            else:
+                assert torch.equal(got["render"], expect)
+    gr.check()
