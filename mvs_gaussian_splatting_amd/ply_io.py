@@ -7,8 +7,10 @@ in the order
     x y z nx ny nz f_dc_0..2 f_rest_0..(3*(deg+1)^2-4) opacity scale_0..2 rot_0..3
 
 with RAW (pre-activation) values, SH coefficients channel-major (``_features_*`` transposed to ``[P, 3, k]`` and
-flattened), normals all zero.  Parity is unpinned (no PLY ships with the reference, ``plyfile`` is not installed):
-the layout is restated from the code cited above.
+flattened), normals all zero.  Pinned to the reference by ``tests/golden/ply_layout.npz``: the structured array the
+reference's ``save_ply`` hands to ``plyfile`` (field names, order, formats, raw bytes) and the tensors its ``load_ply``
+builds from it, captured with a recording stub (``tests/golden/make_golden_ply.py``); only the header text that
+``plyfile`` itself writes in front of that array is restated from that package's published behaviour.
 """
 from __future__ import annotations
 
