@@ -151,3 +151,54 @@ def compare_grads_unmasked(got, ref, n_fragile, label="", ref_masked=None):
             bad[k] = (e, tol)
     print(f"[grad parity, unmasked, {n_fragile} fragile pixels in the loss] {label}: " + "; ".join(rows))
     assert not bad, f"{label}: unmasked gradient error above the per-scene bar: {bad}"
+
+
+def tile_conditioning(model, settings, target, candidates):
+    """Per candidate tile: how far the float32 oracle's COMPOSITING gradients (dL/d screen position, conic, opacity, colour of
+    every Gaussian -- the rows of Appendix A.5) are from the float64 oracle's when the masked L1 loss of tests/grad_util.py
+    is restricted to that one tile.  Nothing of the product enters: it is a property of the scene, the camera and float32.
+
+    Returns (score[len(candidates)], n_fragile[len(candidates)]): score = max over the four tensors of
+    max|g32 - g64| / (max|g64| over ALL candidates); n_fragile = threshold-fragile pixels of the tile (float64 margin)."""
+    from oracle import preprocess_ref, bin_ref, render_tiles_ref
+    names = ("v_xy", "v_conic", "v_opacity", "v_rgb")
+    per_dtype = {}
+    weights = {}
+    for dt in (torch.float64, torch.float32):
+        with torch.no_grad():
+            _, xyz, m2, op, kw = oracle_operator_inputs(model, dt)
+            pre = preprocess_ref(xyz.detach(), op.detach(), settings, **{k: v.detach() for k, v in kw.items()})
+            _, plist, ranges = bin_ref(pre)
+        mids = [pre[k].detach().clone().requires_grad_(True) for k in names]
+        pre = dict(pre, **dict(zip(names, mids)))
+        grads, frag = [], []
+        for t in candidates:
+            col, _, _, margin = render_tiles_ref(pre, plist, ranges, settings, tiles=[int(t)], want_margin=True)
+            if dt == torch.float64:
+                gx = int(pre["grid"][0])
+                ty, tx = divmod(int(t), gx)
+                tm = torch.zeros(1, col.shape[1], col.shape[2], dtype=torch.bool)
+                tm[:, ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16] = True
+                weights[int(t)] = loss_weight(col, target, margin, tm)
+                frag.append(int(((margin <= MARGIN) & tm[0]).sum()))
+            g = torch.autograd.grad(masked_l1(col, target, weights[int(t)]), mids, allow_unused=True)
+            grads.append([torch.zeros_like(m) if x is None else x.detach().double() for x, m in zip(g, mids)])
+        per_dtype[dt] = (grads, frag)
+    g64, frag = per_dtype[torch.float64]
+    g32, _ = per_dtype[torch.float32]
+    # scale: the gradient of the loss over ALL candidate tiles (what compare_grads normalises by, up to the choice of tiles)
+    scale = [float(sum(g[i] for g in g64).abs().max()) for i in range(len(names))]
+    score = []
+    for a, b in zip(g32, g64):
+        score.append(max(float((x - y).abs().max()) / s if s > 0 else 0.0 for x, y, s in zip(a, b, scale)))
+    return score, frag
+
+
+def pick_well_conditioned_tiles(model, settings, target, candidates, n_pick):
+    """The n_pick candidates whose compositing gradients float32 resolves best (tile_conditioning; ties: fewer
+    threshold-fragile pixels first).  The choice depends on the scene, the camera and the ORACLE only."""
+    score, frag = tile_conditioning(model, settings, target, candidates)
+    order = sorted(range(len(candidates)), key=lambda i: (score[i], frag[i]))
+    picked = [candidates[i] for i in order[:n_pick]]
+    return sorted(picked), {"scores_picked_max": max(score[i] for i in order[:n_pick]), "scores_all_max": max(score),
+                            "scores_all_median": sorted(score)[len(score) // 2], "n_candidates": len(candidates)}

@@ -420,10 +420,14 @@ def test_config_C2_full_forward_matches_oracle(gpu_device):
     assert torch.equal(out["n_contrib"][robust], aux["n_contrib"][robust])
 
 
-def _masked_train_step_vs_fp64_oracle(dev, cfg_name, view, tile_step, label, check_stats=False):
+def _masked_train_step_vs_fp64_oracle(dev, cfg_name, view, tile_step, label, check_stats=False, select_from=None):
     """One train step of a BASELINE config at its real size.  The L1 loss is restricted to ~40 tiles spread over the
     image (mask), so that the float64 autograd oracle only has to composite those tiles; the HIP path runs the whole frame
-    and must produce the same pixels there and the same parameter gradients (tests/grad_util.py bar)."""
+    and must produce the same pixels there and the same parameter gradients (tests/grad_util.py bar).
+    select_from = (step_x, step_y): the 40 tiles are not the fixed lattice `tile_step` but the 40 best-conditioned tiles of
+    a denser lattice, ranked by the ORACLE alone (grad_util.pick_well_conditioned_tiles: float32 against float64
+    compositing gradients per tile) -- for the views whose fixed lattice meets a tile no float32 implementation
+    resolves to the 2e-4 cap."""
     from mvs_gaussian_splatting_amd import render, add_densification_stats
     from mvs_gaussian_splatting_amd.synthetic import CONFIGS, make_scene, PipelineParams
     import os
@@ -432,6 +436,13 @@ def _masked_train_step_vs_fp64_oracle(dev, cfg_name, view, tile_step, label, che
     model, cam, bg, target = make_scene(cfg, view=view)
     gx, gy = (cfg.width + 15) // 16, (cfg.height + 15) // 16
     tiles = [ty * gx + tx for ty in range(3, gy, tile_step[1]) for tx in range(5, gx, tile_step[0])]
+    if select_from is not None:
+        from grad_util import pick_well_conditioned_tiles
+        cands = [ty * gx + tx for ty in range(1, gy, select_from[1]) for tx in range(2, gx, select_from[0])]
+        tiles, info = pick_well_conditioned_tiles(model, make_settings(cam, bg, cfg.sh_degree), target, cands, len(tiles))
+        print(f"[tiles] {label}: {len(tiles)} of {info['n_candidates']} candidate tiles by float32-vs-float64 conditioning of "
+              f"the compositing gradients: worst picked {info['scores_picked_max']:.2e}, median of all "
+              f"{info['scores_all_median']:.2e}, worst of all {info['scores_all_max']:.2e}")
     mask = torch.zeros(1, cfg.height, cfg.width)
     for t in tiles:
         ty, tx = divmod(t, gx)
@@ -509,15 +520,16 @@ def test_config_C3_masked_train_step_matches_fp64_oracle(gpu_device):
     assert n == 40
 
 
-@pytest.mark.parametrize("view", [0, 2])
+@pytest.mark.parametrize("view", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_config_C4_masked_train_step_matches_fp64_oracle(gpu_device, view):
     """C4, the config the headline metric is quoted on: 6 M Gaussians, SH degree 3, 1920x1080, forward + backward +
-    densification statistics.  view 0 is the bench's camera; view 2 one of C5's rotated cameras (90 degrees about the
-    cloud centre: the camera stands at the edge of the cloud and looks along its long axis).  Views 1 and 3 are too
-    ill-conditioned for the 2e-4 cap of grad_util on the screen-space gradient (the float32 oracle itself is 8e-5 /
-    1.1e-4 off float64 there); their full-size properties are in test_gpu_c5_views.py."""
+    densification statistics -- from every one of C5's eight cameras (BASELINE configs[4]).  view 0 is the bench's camera,
+    view 2 stands at the edge of the cloud and looks along its long axis: both on the fixed 40-tile lattice.  On that
+    lattice views 1 and 3 meet tiles on which the float32 ORACLE is 8e-5 / 1.1e-4 off float64 in the screen-space gradient
+    (above grad_util's 2e-4 cap on 2 x that error): for the views other than 0 and 2 the 40 tiles are the best-conditioned
+    of a denser lattice of ~130, ranked by the oracle alone; the cap and every bar stay as they are."""
     n, _ = _masked_train_step_vs_fp64_oracle(gpu_device, "C4", view, (15, 14), f"C4 view {view} masked train step",
-                                             check_stats=True)
+                                             check_stats=True, select_from=None if view in (0, 2) else (8, 8))
     assert n == 40
 
 
