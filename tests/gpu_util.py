@@ -119,9 +119,10 @@ def oracle_inputs(model):
     return model.get_xyz, model.get_opacity, model.get_features, model.get_scaling, model.get_rotation
 
 
-def grads_product(dev, model, settings, target, weight, use_cov=False, use_colors=None):
-    """HIP operator forward + backward of the masked L1 loss of tests/grad_util.py (same leaves, same weights)."""
-    from grad_util import masked_l1
+def grads_product(dev, model, settings, target, weight, use_cov=False, use_colors=None, loss_kind="l1"):
+    """HIP operator forward + backward of the masked L1 loss of tests/grad_util.py (same leaves, same weights);
+    loss_kind="linear": of grad_util.weighted_sum (the all-pixel run)."""
+    from grad_util import loss_of
     from mvs_gaussian_splatting_amd import GaussianRasterizer
     leaves = {}
 
@@ -145,5 +146,5 @@ def grads_product(dev, model, settings, target, weight, use_cov=False, use_color
         kw["scales"] = torch.exp(leaf("scaling", model._scaling))
         kw["rotations"] = torch.nn.functional.normalize(leaf("rotation", model._rotation))
     col, radii = GaussianRasterizer(settings)(means3D=xyz, means2D=m2, opacities=torch.sigmoid(op), **kw)
-    masked_l1(col, target, weight).backward()
+    loss_of(col, target, weight, loss_kind).backward()
     return {k: v.grad.detach().cpu() for k, v in leaves.items()}, col.detach().cpu()

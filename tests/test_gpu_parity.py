@@ -132,7 +132,8 @@ def test_empty_and_degenerate_inputs(gpu_device):
 
 def _masked_grad_parity(dev, model, cam, bg, target, deg, label, use_cov=False, use_colors=None, smod=1.0, unmasked=True):
     """float64 oracle defines the loss weights; float32 oracle bounds the conditioning; HIP must meet the bar.
-    unmasked: also run the plain L1 loss over EVERY pixel (the threshold-fragile ones included) at the loose bar."""
+    unmasked: also run a discontinuity-free loss over EVERY pixel (the threshold-fragile ones included): at the same bar
+    when the scene has no fragile pixel, at the per-scene fragile-share bar when it has (tests/grad_util.py)."""
     from gpu_util import grads_product, product_settings
     from grad_util import grads_oracle, compare_grads, compare_grads_unmasked
     st_o = make_settings(cam, bg, deg, scale_modifier=smod)
@@ -152,16 +153,28 @@ def _masked_grad_parity(dev, model, cam, bg, target, deg, label, use_cov=False, 
             assert float(r.abs().max()) > 0.0, k
     assert float(ref["means2D"][:, :2].abs().max()) > 0.0
     if unmasked:
-        ones = torch.ones_like(weight)
-        ref_u, _, _, _ = grads_oracle(model, st_o, target, use_cov=use_cov, use_colors=use_colors, weight=ones)
-        got_u, _ = grads_product(dev, model, product_settings(cam, bg, deg, dev, scale_modifier=smod), target, ones,
-                                 use_cov, use_colors)
-        # what the loss over the ROBUST pixels only (no sign mask) gives in float64: the difference to ref_u is the part of
-        # the gradient that the threshold-fragile pixels carry -- it sets the bar of this scene
-        robust_w = (aux["margin"] > 1e-4)[None].expand_as(weight).to(weight.dtype)
-        ref_r, _, _, _ = grads_oracle(model, st_o, target, use_cov=use_cov, use_colors=use_colors, weight=robust_w) \
-            if n_fragile > 0 else (None, None, None, None)
-        compare_grads_unmasked(got_u, ref_u, n_fragile, label, ref_masked=ref_r)
+        # EVERY pixel in the loss, through a loss that has no discontinuity of its own (grad_util.weighted_sum)
+        from grad_util import linear_weights
+        wts = linear_weights(weight.shape)
+        kw_o = dict(use_cov=use_cov, use_colors=use_colors, loss_kind="linear")
+        ref_u, _, _, _ = grads_oracle(model, st_o, target, weight=wts, **kw_o)
+        got_u, _ = grads_product(dev, model, product_settings(cam, bg, deg, dev, scale_modifier=smod), target, wts,
+                                 use_cov, use_colors, loss_kind="linear")
+        if n_fragile == 0:
+            # no pixel on which float32 and float64 may decide differently: the bar of the masked run, on every pixel
+            ref_u32, _, _, _ = grads_oracle(model, st_o, target, dtype=torch.float32, weight=wts, **kw_o)
+            compare_grads(got_u, ref_u, ref_u32, f"{label}, every pixel in the loss (none threshold-fragile)")
+        else:
+            # what the same loss over the ROBUST pixels gives in float64 (and float32: the conditioning of that part): the
+            # difference to ref_u is the share of the gradient the fragile pixels carry -- it sets the bar of this scene
+            robust_w = wts * (aux["margin"] > 1e-4)[None].to(wts.dtype)
+            ref_r, _, _, _ = grads_oracle(model, st_o, target, weight=robust_w, **kw_o)
+            ref_r32, _, _, _ = grads_oracle(model, st_o, target, dtype=torch.float32, weight=robust_w, **kw_o)
+            compare_grads_unmasked(got_u, ref_u, n_fragile, label, ref_masked=ref_r, ref_masked32=ref_r32)
+            # ... and with ONLY those few pixels out of the loss (no sign mask, no tile mask) the bar is the strict one
+            got_r, _ = grads_product(dev, model, product_settings(cam, bg, deg, dev, scale_modifier=smod), target, robust_w,
+                                     use_cov, use_colors, loss_kind="linear")
+            compare_grads(got_r, ref_r, ref_r32, f"{label}, every pixel but the {n_fragile} threshold-fragile ones in the loss")
     return got, ref, weight, aux
 
 
