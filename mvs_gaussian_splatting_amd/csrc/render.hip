@@ -560,7 +560,11 @@ __device__ __forceinline__ void render_bwd_tile_mb16(const int tile, MbLds& L, i
         float hh[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
+#ifdef BWD_EXP_FLUSH_SLOT0      // attribution build (WRONG rows): every lane reads the zero slot -- no gather, no conflicts
+          const uint32_t at = (c0 + t < p_cnt) ? 0u : 0u;
+#else
           const uint32_t at = (c0 + t < p_cnt) ? p_base + c0 + t : 0u;
+#endif
           f[t] = L.s0[at];
           g[t] = L.s1[at];
           hh[t] = L.s2[at];
@@ -580,7 +584,11 @@ __device__ __forceinline__ void render_bwd_tile_mb16(const int tile, MbLds& L, i
 #pragma unroll
       for (int t = 0; t < 9; ++t) bits |= __float_as_uint(r9[t]);
       const bool nz = (bits << 1) != 0u;      // lanes outside the pass read nothing
+#ifdef BWD_EXP_NO_ROWWRITE      // timing attribution (WRONG): the sums are formed, one lane in a thousand writes its row
+      if (nz && (bits & 0x3ffu) == 0x155u) {
+#else
       if (nz) {
+#endif
         GradRow t;
         t.dmx = r9[0]; t.dmy = r9[1]; t.dcxx = -0.5f * r9[2]; t.dcxy = -r9[3];
         t.dcyy = -0.5f * r9[4]; t.dop = r9[5] * __builtin_amdgcn_exp2f(-p_lo2op); t.dr = r9[6]; t.dg = r9[7];
@@ -682,14 +690,23 @@ __device__ __forceinline__ void render_bwd_tile_mb16(const int tile, MbLds& L, i
         for (int k = 0; k < 4; ++k) {
           // entry: record index in the low byte, slot in the high byte (first slot + rank of the mini-block in the mask)
           const uint32_t sl = above + 1u + (uint32_t)__popc(m & ((1u << (4 * r + k)) - 1u));
+#ifdef BWD_EXP_LIST_PRED       // A/B build: members only (EXEC-masked store) instead of 60 lanes writing the junk entry
+          const uint32_t pp = (idx[r] >> (8 * k)) & 0xffu;
+          if (pp) L.list[4 * r + k][pp] = (uint16_t)((sl << 8) | (uint32_t)lane);
+#else
           L.list[4 * r + k][(idx[r] >> (8 * k)) & 0xffu] = (uint16_t)((sl << 8) | (uint32_t)lane);
+#endif
         }
       __builtin_amdgcn_wave_barrier();
       // two copies of the walk: the 0.99 clamp costs an instruction per pixel and almost no round needs it
       auto walk = [&](auto clamped_c) {
         constexpr bool CLAMPED = decltype(clamped_c)::value;
         auto fetch = [&](uint32_t e, float4& a, float4& b, float& cb) {
+#ifdef BWD_EXP_REC_BANK         // attribution build (WRONG gradients): bank mb reads record mb -- no gather conflicts
+          const char* rp = reinterpret_cast<const char*>(L.R) + 48u * ((e & 0u) + (uint32_t)mb);
+#else
           const char* rp = reinterpret_cast<const char*>(L.R) + 48u * (e & 0xffu);
+#endif
           a = *reinterpret_cast<const float4*>(rp);
           b = *reinterpret_cast<const float4*>(rp + 16);
           cb = *reinterpret_cast<const float*>(rp + 32);
@@ -744,9 +761,15 @@ __device__ __forceinline__ void render_bwd_tile_mb16(const int tile, MbLds& L, i
           // values and all four write them (same address, same data): no EXEC change, the step stays one basic block
           // (-3 %, profiles/r03/ab_bwd_mb16_step.txt; two steps per iteration in one block: no better, the odd lengths cost
           // a step)
+#ifdef BWD_EXP_SLOT_LANE        // attribution build (WRONG rows): every bank writes a slot of its own -- no store conflicts
+          L.s0[1 + mb] = make_float4(v[0], v[1], v[2], v[3]);
+          L.s1[1 + mb] = make_float4(v[4], v[5], v[6], v[7]);
+          L.s2[1 + mb] = v[8];
+#else
           L.s0[e0 >> 8] = make_float4(v[0], v[1], v[2], v[3]);
           L.s1[e0 >> 8] = make_float4(v[4], v[5], v[6], v[7]);
           L.s2[e0 >> 8] = v[8];
+#endif
         };
         uint32_t e0 = mylist[0], e1 = mylist[1];
         float4 a, b, an, bn;
@@ -763,7 +786,9 @@ __device__ __forceinline__ void render_bwd_tile_mb16(const int tile, MbLds& L, i
       PROF_T(t_p1);
       PROF_ADD(1, t_p0, t_p1);
       PROF_CNT(6, nmax);
+#ifndef BWD_EXP_NO_FLUSH         // timing attribution (WRONG): no row sums, no rows
       if (pending) flush_rows();
+#endif
       PROF_T(t_p1b);
       PROF_ADD(3, t_p1, t_p1b);
       if (clamp) walk(std::true_type{}); else walk(std::false_type{});

@@ -51,3 +51,40 @@ with torch.no_grad():
     pr.disable()
     torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+# ---- where the host time of a render() frame goes: the two native calls of the verified mode, timed from Python -------------
+from mvs_gaussian_splatting_amd import _lib  # noqa: E402
+lib = _lib.load()
+acc = {"gsr_forward": 0.0, "gsr_event_wait": 0.0}
+orig = {k: getattr(lib, k) for k in acc}
+
+
+def _timed(name):
+    fn = orig[name]
+
+    def wrapped(*a):
+        t = time.perf_counter()
+        r = fn(*a)
+        acc[name] += time.perf_counter() - t
+        return r
+    return wrapped
+
+
+for k in acc:
+    setattr(lib, k, _timed(k))
+with torch.no_grad():
+    for rep in range(2):
+        for k in acc:
+            acc[k] = 0.0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(4 * n):
+            render(cam, model, pipe, bg)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        per = 1e3 / (4 * n)
+        print(f"{cfgname} render() frame: {per * (t2 - t0):.4f} ms wall; host: gsr_forward {per * acc['gsr_forward']:.4f} ms (enqueue of the "
+              f"whole frame), gsr_event_wait {per * acc['gsr_event_wait']:.4f} ms (scan kernel's event), Python around them "
+              f"{per * ((t1 - t0) - acc['gsr_forward'] - acc['gsr_event_wait']):.4f} ms")
+for k in acc:
+    setattr(lib, k, orig[k])

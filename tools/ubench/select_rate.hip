@@ -3,6 +3,7 @@
 //   the mask in VCC or in an SGPR pair, written by a VALU compare or by a SALU s_and_b64 right in front of the select
 //   (the backward's `ok = pos <= last && alpha >= 1/255`), an EXEC-masked region instead of a select, and a few
 //   candidates for folding sums over the four lanes of a DPP bank.
+// (every asm block that holds an s_and_b64 / s_and_saveexec_b64 declares "scc" clobbered: the loop branch lives there)
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench/select_rate.hip -o tools/ubench/bin/select_rate && tools/ubench/bin/select_rate
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* clk, in
           "s_and_b64 vcc, s[20:21], s[22:23]\n v_cndmask_b32 %2, %2, %9, vcc\n s_and_b64 vcc, s[20:21], s[22:23]\n v_cndmask_b32 %3, %3, %9, vcc\n"
           "s_and_b64 vcc, s[20:21], s[22:23]\n v_cndmask_b32 %4, %4, %9, vcc\n s_and_b64 vcc, s[20:21], s[22:23]\n v_cndmask_b32 %5, %5, %9, vcc\n"
           : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b)
-          : "vcc", "s20", "s21", "s22", "s23");
+          : "vcc", "scc", "s20", "s21", "s22", "s23");
     } else if (MODE == SEL_SGPR_SALU) {
       asm volatile(
           "v_cmp_lt_f32 s[20:21], %0, %8\n v_cmp_lt_f32 s[22:23], %1, %8\n"
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* clk, in
           "s_and_b64 s[24:25], s[20:21], s[22:23]\n v_cndmask_b32_e64 %2, %2, %9, s[24:25]\n s_and_b64 s[26:27], s[20:21], s[22:23]\n v_cndmask_b32_e64 %3, %3, %9, s[26:27]\n"
           "s_and_b64 s[24:25], s[20:21], s[22:23]\n v_cndmask_b32_e64 %4, %4, %9, s[24:25]\n s_and_b64 s[26:27], s[20:21], s[22:23]\n v_cndmask_b32_e64 %5, %5, %9, s[26:27]\n"
           : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b)
-          : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+          : "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
     } else if (MODE == SEL_SGPR_VALU) {
       asm volatile(
           "v_cmp_lt_f32 s[20:21], %0, %8\n v_cndmask_b32_e64 %0, %0, %9, s[20:21]\n v_cmp_lt_f32 s[22:23], %1, %8\n v_cndmask_b32_e64 %1, %1, %9, s[22:23]\n"
@@ -71,23 +72,23 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* clk, in
           "v_cmp_lt_f32 s[20:21], %4, %8\n v_cndmask_b32_e64 %4, %4, %9, s[20:21]\n v_cmp_lt_f32 s[22:23], %5, %8\n v_cndmask_b32_e64 %5, %5, %9, s[22:23]\n"
           "v_cmp_lt_f32 s[24:25], %6, %8\n v_cndmask_b32_e64 %6, %6, %9, s[24:25]\n v_cmp_lt_f32 s[26:27], %7, %8\n v_cndmask_b32_e64 %7, %7, %9, s[26:27]\n"
           : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b)
-          : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+          : "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
     } else if (MODE == EXEC_REGION) {
       asm volatile(REP4(
           "v_cmp_lt_f32 vcc, %8, %0\n s_and_saveexec_b64 s[20:21], vcc\n"
           "v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n v_fma_f32 %4, %4, %8, %9\n"
           "s_mov_b64 exec, s[20:21]\n")
-          : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b) : "vcc", "s20", "s21");
+          : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b) : "vcc", "scc", "s20", "s21");
     } else if (MODE == CMP2_AND_SEL_VCC) {
       asm volatile(REP4(
           "v_cmp_le_u32 s[20:21], %0, %8\n v_cmp_le_f32 s[22:23], %9, %1\n s_and_b64 vcc, s[20:21], s[22:23]\n v_cndmask_b32 %1, 0, %1, vcc\n")
           : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b)
-          : "vcc", "s20", "s21", "s22", "s23");
+          : "vcc", "scc", "s20", "s21", "s22", "s23");
     } else if (MODE == CMP2_AND_SEL_SGPR) {
       asm volatile(REP4(
           "v_cmp_le_u32 s[20:21], %0, %8\n v_cmp_le_f32 s[22:23], %9, %1\n s_and_b64 s[24:25], s[20:21], s[22:23]\n v_cndmask_b32_e64 %1, 0, %1, s[24:25]\n")
           : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b)
-          : "s20", "s21", "s22", "s23", "s24", "s25");
+          : "scc", "s20", "s21", "s22", "s23", "s24", "s25");
     } else if (MODE == MUL_MASK) {
       asm volatile(
           "v_cmp_lt_f32 vcc, %0, %8\n v_mul_f32 %0, %0, %9\n v_cmp_lt_f32 vcc, %1, %8\n v_mul_f32 %1, %1, %9\n"
