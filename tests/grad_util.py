@@ -108,8 +108,9 @@ def grads_oracle(model, settings, target, *, dtype=torch.float64, use_cov=False,
     return grads, weight, aux, col.detach()
 
 
-def compare_grads(got, ref, ref32=None, label=""):
-    """Assert max|got - ref| / max|ref| <= max(1e-5, 2 e32) for every tensor; print the table that ran."""
+def compare_grads(got, ref, ref32=None, label="", e32_factor=2.0):
+    """Assert max|got - ref| / max|ref| <= max(1e-5, e32_factor x e32) for every tensor (e32_factor = 2 everywhere except
+    the one comparison documented at its call site); print the table that ran."""
     rows, bad = [], {}
     for k, r in ref.items():
         if r.numel() == 0:
@@ -123,7 +124,7 @@ def compare_grads(got, ref, ref32=None, label=""):
             continue
         e = float((g - r).abs().max()) / scale
         e32 = float((ref32[k].double() - r).abs().max()) / scale if ref32 is not None else 0.0
-        tol = max(TOL, 2.0 * e32)
+        tol = max(TOL, e32_factor * e32)
         assert tol <= ESCAPE_CAP, (f"{label}: {k} is too ill-conditioned to test (the float32 oracle itself is {e32:.2e} "
                                    f"off float64): the scene must be made better conditioned, not the bar wider")
         rows.append(f"{k}: err {e:.2e} (float32 oracle {e32:.2e}, bar {tol:.2e})")
@@ -168,6 +169,48 @@ def compare_grads_unmasked(got, ref, n_fragile, label="", ref_masked=None, ref_m
             bad[k] = (e, tol)
     print(f"[grad parity, every pixel in the loss, {n_fragile} of them threshold-fragile] {label}: " + "; ".join(rows))
     assert not bad, f"{label}: all-pixel gradient error above the per-scene bar: {bad}"
+
+
+class SubModel:
+    """The raw parameters of a subset of a model's Gaussians (index order kept: depth ties sort as in the full model)."""
+
+    def __init__(self, model, idx):
+        self.index = idx
+        for k in RAW:
+            setattr(self, k, getattr(model, k).detach()[idx].contiguous())
+
+
+def full_frame_lists(model, settings):
+    """Float64 and float32 oracle preprocess + binning of the WHOLE model without autograd (seconds at 6 M Gaussians):
+    -> {dtype: (radii[P], point_list, ranges)}.  What the full-size tests need of all P Gaussians (radii, which Gaussians
+    reach which tile); the differentiable oracle then runs on the few that reach the tiles in the loss."""
+    from oracle import preprocess_ref, bin_ref
+    out = {}
+    for dt in (torch.float64, torch.float32):
+        with torch.no_grad():
+            _, xyz, _, op, kw = oracle_operator_inputs(model, dt)
+            pre = preprocess_ref(xyz.detach(), op.detach(), settings, **{k: v.detach() for k, v in kw.items()})
+            _, plist, ranges = bin_ref(pre)
+        out[dt] = (pre["radii"].clone(), plist, ranges)
+    return out
+
+
+def members_of_tiles(lists, tiles):
+    """Sorted indices of every Gaussian in the list of one of `tiles`, in the float64 OR the float32 oracle's binning."""
+    import numpy as np
+    parts = [pl[int(rg[t, 0]):int(rg[t, 1])] for (_, pl, rg) in lists.values() for t in tiles]
+    idx = np.unique(np.concatenate(parts).astype(np.int64)) if parts else np.zeros(0, np.int64)
+    return torch.from_numpy(idx)
+
+
+def expand_grads(grads, idx, P):
+    """Gradients of a SubModel's Gaussians scattered into all-zero tensors for the P Gaussians of the full model."""
+    out = {}
+    for k, g in grads.items():
+        full = torch.zeros((P,) + tuple(g.shape[1:]), dtype=g.dtype)
+        full[idx] = g
+        out[k] = full
+    return out
 
 
 def tile_conditioning(model, settings, target, candidates):

@@ -204,3 +204,92 @@ def test_c_oracle_is_clean_under_asan_and_ubsan():
     r = subprocess.run(["make", "-C", cdir, "asan"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "asan/ubsan clean" in r.stdout
+
+
+# ---- the comparison rules of tests/grad_util.py themselves, with the float32 oracle standing in for a product ---------------
+def test_all_pixel_rules_hold_for_an_independent_float32_implementation():
+    """The all-pixel run of the GPU parity tests (grad_util: discontinuity-free loss over EVERY pixel; strict bar without
+    threshold-fragile pixels, per-scene bar with them) must at least accept the float32 oracle -- an implementation that
+    shares nothing with the HIP kernels -- and must reject a gradient that is off by a percent."""
+    import pytest
+    from conftest import small_scene, make_settings
+    from grad_util import (grads_oracle, compare_grads, compare_grads_unmasked, linear_weights)
+    seen = set()
+    for seed in (0, 2):
+        model, cam, _, target = small_scene(P=1200, sh_degree=1, width=112, height=80, scale=0.06, seed=seed)
+        bg = torch.tensor([0.3, 0.1, 0.2])
+        st = make_settings(cam, bg, 1)
+        _, weight, aux, _ = grads_oracle(model, st, target)
+        n_fragile = int((aux["margin"] <= 1e-4).sum())
+        wts = linear_weights(weight.shape)
+        assert float(wts.abs().min()) > 0.0 and wts.shape == weight.shape
+        kw = dict(loss_kind="linear")
+        ref_u, _, _, _ = grads_oracle(model, st, target, weight=wts, **kw)
+        got_u, _, _, _ = grads_oracle(model, st, target, dtype=torch.float32, weight=wts, **kw)
+        if n_fragile == 0:
+            seen.add("strict")
+            compare_grads(got_u, ref_u, got_u, f"seed {seed}")
+            bad = {k: (v * 1.01 if k == "xyz" else v) for k, v in got_u.items()}
+            with pytest.raises(AssertionError):
+                compare_grads(bad, ref_u, got_u, f"seed {seed}, xyz off by 1 %")
+        else:
+            seen.add("fragile")
+            robust_w = wts * (aux["margin"] > 1e-4)[None].to(wts.dtype)
+            ref_r, _, _, _ = grads_oracle(model, st, target, weight=robust_w, **kw)
+            ref_r32, _, _, _ = grads_oracle(model, st, target, dtype=torch.float32, weight=robust_w, **kw)
+            compare_grads_unmasked(got_u, ref_u, n_fragile, f"seed {seed}", ref_masked=ref_r, ref_masked32=ref_r32)
+            compare_grads(ref_r32, ref_r, ref_r32, f"seed {seed}, robust pixels only")
+            bad = {k: (v * 1.5 if k == "opacity" else v) for k, v in got_u.items()}
+            with pytest.raises(AssertionError):
+                compare_grads_unmasked(bad, ref_u, n_fragile, f"seed {seed}, opacity off by half", ref_masked=ref_r,
+                                       ref_masked32=ref_r32)
+    assert seen, "no scene ran"
+
+
+def test_tiles_are_ranked_by_the_oracle_alone():
+    """grad_util.pick_well_conditioned_tiles: the picked tiles are the candidates with the smallest float32-vs-float64
+    disagreement of the compositing gradients; the worst picked score is no larger than the worst of all."""
+    from conftest import small_scene, make_settings
+    from grad_util import pick_well_conditioned_tiles, tile_conditioning
+    model, cam, bg, target = small_scene(P=2000, sh_degree=1, width=160, height=96, view=1)
+    st = make_settings(cam, bg, 1)
+    gx, gy = 10, 6
+    cands = [ty * gx + tx for ty in range(0, gy, 2) for tx in range(0, gx, 2)]
+    tiles, info = pick_well_conditioned_tiles(model, st, target, cands, 6)
+    assert len(tiles) == 6 and set(tiles) <= set(cands) and tiles == sorted(tiles)
+    assert info["scores_picked_max"] <= info["scores_all_max"] and info["n_candidates"] == len(cands)
+    score, frag = tile_conditioning(model, st, target, cands)
+    assert len(score) == len(cands) == len(frag) and min(score) >= 0.0
+    best = sorted(range(len(cands)), key=lambda i: (score[i], frag[i]))[:6]
+    assert sorted(cands[i] for i in best) == tiles
+
+
+def test_oracle_on_the_gaussians_of_the_masked_tiles_equals_the_oracle_on_the_whole_model():
+    """The full-size GPU tests differentiate the oracle only over the Gaussians that are in the list of a masked tile
+    (grad_util.SubModel / members_of_tiles / expand_grads).  On a small scene, against the oracle run on every Gaussian:
+    same image in the masked tiles, same weights, same gradients (zero for every Gaussian outside the subset)."""
+    from grad_util import grads_oracle, full_frame_lists, members_of_tiles, SubModel, expand_grads
+    model, cam, _, target = small_scene(P=2500, sh_degree=2, width=160, height=112, scale=0.05, view=1)
+    bg = torch.tensor([0.2, 0.3, 0.1])
+    st = make_settings(cam, bg, 2)
+    gx = 10
+    tiles = [1 * gx + 2, 3 * gx + 7, 5 * gx + 4, 6 * gx + 9]
+    mask = torch.zeros(1, 112, 160)
+    for t in tiles:
+        ty, tx = divmod(t, gx)
+        mask[:, ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16] = 1.0
+    ref, weight, aux, col = grads_oracle(model, st, target, tiles=tiles, tile_mask=mask)
+    lists = full_frame_lists(model, st)
+    assert torch.equal(lists[torch.float64][0], aux["radii"])
+    idx = members_of_tiles(lists, tiles)
+    assert 0 < idx.numel() < 2500
+    sub = SubModel(model, idx)
+    ref_s, weight_s, aux_s, col_s = grads_oracle(sub, st, target, tiles=tiles, tile_mask=mask)
+    assert torch.equal(weight, weight_s) and torch.equal(aux["margin"], aux_s["margin"])
+    assert torch.allclose(col, col_s, rtol=0, atol=1e-14)
+    full = expand_grads(ref_s, idx, 2500)
+    outside = torch.ones(2500, dtype=torch.bool)
+    outside[idx] = False
+    for k, r in ref.items():
+        assert not r[outside].any(), k                   # the whole-model oracle agrees: nothing outside the subset
+        assert torch.allclose(full[k], r, rtol=1e-12, atol=1e-18), k
