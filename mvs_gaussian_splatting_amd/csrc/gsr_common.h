@@ -113,7 +113,10 @@ constexpr int PRE_BLOCK = 256;      // Gaussians per preprocess / duplicate bloc
 
 // ---- workspace layouts (host + device agree through these helpers) -------------------------
 constexpr int SORT_THREADS = 512;
-constexpr int SORT_ITEMS = 8;
+#ifndef GSR_SORT_ITEMS
+#define GSR_SORT_ITEMS 8          // A/B builds only (tools/build_variant_all.sh -DGSR_SORT_ITEMS=4): items per lane of a sort block
+#endif
+constexpr int SORT_ITEMS = GSR_SORT_ITEMS;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;   // keys per sort block
 constexpr int RADIX_BITS = 9;   // widest digit: 45-bit keys at 1080p (13 tile bits + 32 depth bits) sort in 5 passes
 constexpr int RADIX = 1 << RADIX_BITS;
