@@ -189,11 +189,7 @@ __device__ __forceinline__ void walk_lists(const uint16_t* __restrict__ mylist, 
                                            const float pyf, float& T, float& Cr, float& Cg, float& Cb, uint32_t& last) {
   auto ldA = [&](uint32_t e) { return *reinterpret_cast<const float4*>(sA + e); };
   auto ldB = [&](uint32_t e) { return *reinterpret_cast<const float4*>(sB + e); };
-#ifdef FWD_EXP_SC16          // A/B build: colour-b array of 16-byte stride (no shift per pair, +3 KB of LDS per workgroup)
-  auto ldC = [&](uint32_t e) { return *reinterpret_cast<const float*>(sC + e); };
-#else
   auto ldC = [&](uint32_t e) { return *reinterpret_cast<const float*>(sC + (e >> 2)); };
-#endif
   uint32_t e0 = mylist[0], e1 = mylist[1];
   float4 a0 = ldA(e0), b0 = ldB(e0);
   float c0 = ldC(e0);
@@ -208,13 +204,8 @@ __device__ __forceinline__ void walk_lists(const uint16_t* __restrict__ mylist, 
   }
 }
 
-#if defined(FWD_EXP_SC16) || defined(FWD_EXP_OCC7)
-#define FWD_MIN_BLOCKS(track) 7
-#else
-#define FWD_MIN_BLOCKS(track) ((track) ? 7 : 8)
-#endif
 template <bool STATS, bool TRACK>
-__global__ __launch_bounds__(256, FWD_MIN_BLOCKS(TRACK)) void render_fwd_kernel(int W, int H, int grid_x, int cull_miniblocks,
+__global__ __launch_bounds__(256, TRACK ? 7 : 8) void render_fwd_kernel(int W, int H, int grid_x, int cull_miniblocks,
                                                          const uint32_t* __restrict__ tile_order,
                                                          const uint2* __restrict__ ranges,
                                                          const uint32_t* __restrict__ point_list,
@@ -228,11 +219,7 @@ __global__ __launch_bounds__(256, FWD_MIN_BLOCKS(TRACK)) void render_fwd_kernel(
                                                          unsigned long long* __restrict__ stats) {
   __shared__ float4 sA[QROUND + 1];
   __shared__ float4 sB[QROUND + 1];
-#ifdef FWD_EXP_SC16
-  __shared__ float4 sC[QROUND + 1];
-#else
   __shared__ float sC[QROUND + 4];
-#endif
   __shared__ __attribute__((aligned(16))) uint16_t sList[16][QLIST];
   __shared__ uint4 sCnt[4];             // per wave: counts of the 16 mini-blocks, one byte each
   __shared__ uint32_t sFlag[2][4];      // [0] any opacity > ALPHA_MAX in the round, [1] tile_max partials
@@ -256,11 +243,7 @@ __global__ __launch_bounds__(256, FWD_MIN_BLOCKS(TRACK)) void render_fwd_kernel(
   if (tid == 0) {
     sA[QDUMMY] = make_float4(0.f, 0.f, 0.f, 0.f);
     sB[QDUMMY] = make_float4(0.f, -__builtin_inff(), 0.f, 0.f);      // log2(opacity) = -inf: alpha = exp2(-inf) = 0
-#ifdef FWD_EXP_SC16
-    sC[QDUMMY] = make_float4(0.f, 0.f, 0.f, 0.f);
-#else
     sC[QDUMMY] = 0.0f;
-#endif
   }
   // this 16-lane group's mini-block: row / column of 4x4 blocks inside the tile (bit 4 * blk_r + blk_c of the reach mask)
   const int blk_r = 2 * (wid >> 1) + (grp >> 1), blk_c = 2 * (wid & 1) + (grp & 1);
@@ -290,11 +273,7 @@ __global__ __launch_bounds__(256, FWD_MIN_BLOCKS(TRACK)) void render_fwd_kernel(
     make_lds(st, lr);
     sA[tid] = lr.A;
     sB[tid] = lr.B;
-#ifdef FWD_EXP_SC16
-    sC[tid].x = st.q2.x;
-#else
     sC[tid] = st.q2.x;
-#endif
     uint32_t m16 = have ? miniblock_mask(st.q0.x - tx0, st.q0.y - ty0, st.q0.z, st.kk, st.isyy, st.q2.y, st.q2.z) : 0u;
     if (!cull_miniblocks) m16 = have ? 0xffffu : 0u;      // debug (GSR_DEBUG_NO_MINIBLOCK_CULL): every pair is evaluated
     // the backward walks the same (instance, mini-block) pairs: it reads the masks instead of computing them again
