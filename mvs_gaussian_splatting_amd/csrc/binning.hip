@@ -334,24 +334,43 @@ __device__ inline uint32_t emitf_load(EmitBlockLds& L, uint32_t V, const uint2* 
   return L.incl[EMIT_GB - 1];
 }
 
-// (tile id, Gaussian index) of the block's output slot o < n_out: the owning Gaussian by binary search in the block's
-// inclusive scan, the tile from the slot's rank inside the rect (y outer, x inner) -- emit_instances' expansion
-__device__ inline uint2 emitf_instance(const EmitBlockLds& L, uint32_t o, int grid_x) {
-  int lo = 0, hi = EMIT_GB - 1;       // smallest j with incl[j] > o
-#pragma unroll
-  for (int it = 0; it < 10; ++it) {
-    const int mid = (lo + hi) >> 1;
-    if (L.incl[mid] > o) hi = mid; else lo = mid + 1;
+// Tiles of a staged Gaussian, in emission order (y outer, x inner): f(k, tile id) for its k-th instance.
+//   rects of at most MASK_TILES tiles: the set bits of the tile mask, ascending;
+//   larger rects (every tile of the rect): the caller walks k itself (emitf_big_tile).
+template <typename F>
+__device__ inline void emitf_small_tiles(uint32_t mn, uint32_t wh, uint32_t mask, int grid_x, F&& f) {
+  const uint32_t w = max(wh & 0xffffu, 1u);
+  const float rw = 1.0f / (float)w;
+  const uint32_t x0 = mn & 0xffffu, y0 = mn >> 16;
+  uint32_t m = mask, k = 0;
+  while (m) {
+    const uint32_t bit = (uint32_t)__ffs((int)m) - 1u;
+    m &= m - 1u;
+    const uint32_t q = (uint32_t)(((float)bit + 0.5f) * rw);      // bit / w (exact: bit < 32)
+    f(k, (y0 + q) * (uint32_t)grid_x + x0 + (bit - q * w));
+    ++k;
   }
-  const int j = lo;
-  const uint32_t first = j ? L.incl[j - 1] : 0u;
-  const uint32_t wh = L.wh[j];
-  const uint32_t k = bin_kth(wh, L.mask[j], o - first);
+}
+__device__ inline uint32_t emitf_big_tile(uint32_t mn, uint32_t wh, uint32_t k, int grid_x) {
   const uint32_t w = max(wh & 0xffffu, 1u);
   const uint32_t q = (uint32_t)(((float)k + 0.5f) * (1.0f / (float)w));   // k / w (exact for k < 2^20)
-  const uint32_t mn = L.mn[j];
-  const uint32_t x = (mn & 0xffffu) + (k - q * w), y = (mn >> 16) + q;
-  return make_uint2(y * (uint32_t)grid_x + x, L.g[j]);
+  return ((mn >> 16) + q) * (uint32_t)grid_x + (mn & 0xffffu) + (k - q * w);
+}
+__device__ inline bool emitf_is_big(uint32_t wh) { return (wh & 0xffffu) * (wh >> 16) > MASK_TILES; }
+
+// The block's Gaussians with more than MASK_TILES tiles, listed for the cooperative loops (order irrelevant: every
+// instance has its own slot).  Returns their number; big_list[] holds their positions in the block.
+__device__ inline uint32_t emitf_list_big(const EmitBlockLds& L, uint16_t* big_list, uint32_t* big_count) {
+  const int tid = threadIdx.x;
+  if (tid == 0) *big_count = 0;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int j = 2 * tid + u;
+    if (emitf_is_big(L.wh[j])) big_list[atomicAdd(big_count, 1u)] = (uint16_t)j;
+  }
+  __syncthreads();
+  return *big_count;
 }
 
 template <int BITS>
@@ -363,14 +382,31 @@ __global__ __launch_bounds__(EMITF_THREADS) void count_digits_kernel(const uint3
   constexpr int RADIX = 1 << BITS;
   __shared__ EmitBlockLds L;
   __shared__ uint32_t h[RADIX];
+  __shared__ uint16_t big_list[EMIT_GB];
+  __shared__ uint32_t big_count;
   const uint32_t V = total[TOTAL_V];
   const int tid = threadIdx.x;
 #pragma unroll
   for (int d = tid; d < RADIX; d += EMITF_THREADS) h[d] = 0;
   if (blockIdx.x * (uint32_t)EMIT_GB < V) {      // (uniform) blocks past the count publish an all-zero column: the row scan
     const uint2* __restrict__ dval = total[TOTAL_TOP_PASS_N] ? d4 : d3;      // runs over the columns of the capacity
-    const uint32_t n_out = emitf_load(L, V, dval, bin, grid_x);              // (its two barriers also cover h[])
-    for (uint32_t o = (uint32_t)tid; o < n_out; o += EMITF_THREADS) atomicAdd(&h[emitf_instance(L, o, grid_x).x & mask], 1u);
+    emitf_load(L, V, dval, bin, grid_x);                                     // (its two barriers also cover h[])
+    // every lane counts the tiles of its two Gaussians (2.1 each on the bench cloud); the few large rects are walked by
+    // the whole block
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = 2 * tid + u;
+      const uint32_t wh = L.wh[j];
+      if (!emitf_is_big(wh))
+        emitf_small_tiles(L.mn[j], wh, L.mask[j], grid_x, [&](uint32_t, uint32_t tile) { atomicAdd(&h[tile & mask], 1u); });
+    }
+    const uint32_t nbig = emitf_list_big(L, big_list, &big_count);
+    for (uint32_t b = 0; b < nbig; ++b) {
+      const int j = big_list[b];
+      const uint32_t mn = L.mn[j], wh = L.wh[j];
+      const uint32_t n = (wh & 0xffffu) * (wh >> 16);
+      for (uint32_t k = (uint32_t)tid; k < n; k += EMITF_THREADS) atomicAdd(&h[emitf_big_tile(mn, wh, k, grid_x) & mask], 1u);
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -393,18 +429,24 @@ __global__ __launch_bounds__(EMITF_THREADS) void emit_scatter_kernel(const uint3
   if (blockIdx.x * (uint32_t)EMIT_GB >= V) return;      // grid sized for a capacity (uniform exit: no barrier crossed)
   const uint2* __restrict__ dval = total[TOTAL_TOP_PASS_N] ? d4 : d3;
   __shared__ EmitBlockLds L;
-  __shared__ uint32_t xbuf[CHUNK];             // exchange buffer: tile ids first, then reused for the indices
+  // the chunk's instances in emission order (every Gaussian writes its own: no search per output slot); the tile ids'
+  // array then serves as the exchange buffer of the scatter
+  __shared__ uint32_t stage_k[CHUNK];
+  __shared__ uint32_t stage_v[CHUNK];
   __shared__ uint32_t wave_hist[NW][RADIX];    // per-wave digit counts, then exclusive wave prefixes
   __shared__ uint32_t digit_start[RADIX];      // first local slot of every digit (this chunk)
   __shared__ uint32_t global_base[RADIX];      // global position of the chunk's first item of the digit
   __shared__ uint32_t block_base[RADIX];       // ... of the BLOCK's first item of the digit (digit base + row prefix)
   __shared__ uint32_t carried[RADIX];          // items of the digit in the block's earlier chunks
   __shared__ uint32_t scan_tmp[NW];
+  __shared__ uint16_t big_list[EMIT_GB];
+  __shared__ uint32_t big_count;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
   constexpr int BPT = RADIX >= EMITF_THREADS ? RADIX / EMITF_THREADS : 1;
   const bool owner = tid * BPT < RADIX;
 
   const uint32_t n_out = emitf_load(L, V, dval, bin, grid_x);
+  const uint32_t nbig = emitf_list_big(L, big_list, &big_count);
   {   // digit bases = exclusive scan of the digit totals; + this block's row prefix (the scanned dhist column)
     uint32_t tot[BPT], tmine = 0;
 #pragma unroll
@@ -430,29 +472,63 @@ __global__ __launch_bounds__(EMITF_THREADS) void emit_scatter_kernel(const uint3
       }
     }
   }
+  // this thread's two Gaussians (kept in registers across the chunks)
+  uint32_t my_first[2], my_n[2], my_mn[2], my_wh[2], my_mask[2], my_g[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int j = 2 * tid + u;
+    my_wh[u] = L.wh[j];
+    my_mn[u] = L.mn[j];
+    my_mask[u] = L.mask[j];
+    my_g[u] = L.g[j];
+    const uint32_t end = L.incl[j];
+    my_first[u] = j ? L.incl[j - 1] : 0u;
+    my_n[u] = emitf_is_big(my_wh[u]) ? 0u : end - my_first[u];      // 0: nothing to do on the per-lane path
+  }
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   for (uint32_t c0 = 0; c0 < n_out; c0 += CHUNK) {
-    __syncthreads();       // the previous chunk is done with xbuf / wave_hist / digit_start; block_base / carried are written
+    __syncthreads();       // the previous chunk is done with the stages / wave_hist / digit_start; block_base / carried are written
 #pragma unroll
     for (int w = 0; w < NW; ++w)
 #pragma unroll
       for (int d = tid; d < RADIX; d += EMITF_THREADS) wave_hist[w][d] = 0;
+    // ---- the chunk's instances, slot by slot: every Gaussian that reaches into [c0, c0 + CHUNK) writes its own ----
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (my_n[u] && my_first[u] < c0 + CHUNK && my_first[u] + my_n[u] > c0) {
+        const uint32_t first = my_first[u], g = my_g[u];
+        emitf_small_tiles(my_mn[u], my_wh[u], my_mask[u], grid_x, [&](uint32_t k, uint32_t tile) {
+          const uint32_t sl = first + k - c0;      // wraps for slots in front of the window
+          if (sl < (uint32_t)CHUNK) { stage_k[sl] = tile; stage_v[sl] = g; }
+        });
+      }
+    }
+    for (uint32_t b = 0; b < nbig; ++b) {         // large rects: the whole block walks the part inside the window
+      const int j = big_list[b];
+      const uint32_t first = j ? L.incl[j - 1] : 0u, end = L.incl[j];
+      if (first >= c0 + CHUNK || end <= c0) continue;     // (uniform)
+      const uint32_t mn = L.mn[j], wh = L.wh[j], g = L.g[j];
+      const uint32_t lo = max(first, c0), hi = min(end, c0 + (uint32_t)CHUNK);
+      for (uint32_t o = lo + (uint32_t)tid; o < hi; o += EMITF_THREADS) {
+        stage_k[o - c0] = emitf_big_tile(mn, wh, o - first, grid_x);
+        stage_v[o - c0] = g;
+      }
+    }
     __syncthreads();
     // item i of lane l of wave w is output slot c0 + w * 512 + i * 64 + l: (i, l) lexicographic == emission order
-    const uint32_t wbase = c0 + (uint32_t)wid * (WAVE * EMITF_ITEMS);
+    const uint32_t wloc = (uint32_t)wid * (WAVE * EMITF_ITEMS);
+    const uint32_t count = min((uint32_t)CHUNK, n_out - c0);
     uint32_t k[EMITF_ITEMS], v[EMITF_ITEMS], rank[EMITF_ITEMS];
 #pragma unroll
     for (int i = 0; i < EMITF_ITEMS; ++i) {
-      const uint32_t o = wbase + i * WAVE + lane;
-      const uint2 kv = emitf_instance(L, min(o, n_out - 1u), grid_x);
-      k[i] = kv.x;
-      v[i] = kv.y;
+      const uint32_t sl = min(wloc + i * WAVE + lane, count - 1u);
+      k[i] = stage_k[sl];
+      v[i] = stage_v[sl];
     }
     // stable rank of every item among the wave's items with the same digit (radix_scatter_kernel's wave match)
 #pragma unroll
     for (int i = 0; i < EMITF_ITEMS; ++i) {
-      const uint32_t o = wbase + i * WAVE + lane;
-      const bool ok = o < n_out;
+      const bool ok = wloc + i * WAVE + lane < count;
       const uint32_t d = k[i] & mask;
       unsigned long long peers = __ballot(ok);
       if (!ok) peers = ~peers;
@@ -471,7 +547,7 @@ __global__ __launch_bounds__(EMITF_THREADS) void emit_scatter_kernel(const uint3
       }
       rank[i] = old + before;
     }
-    __syncthreads();
+    __syncthreads();       // also: every read of the stages is done
     {   // digit totals of the chunk over the waves -> exclusive wave prefixes, local digit starts, global positions
       uint32_t dsum[BPT], mine = 0;
 #pragma unroll
@@ -511,42 +587,29 @@ __global__ __launch_bounds__(EMITF_THREADS) void emit_scatter_kernel(const uint3
       }
     }
     __syncthreads();
-    // exchange through LDS so that every digit's run leaves the block contiguously
+    // exchange through LDS so that every digit's run leaves the block contiguously (tile ids through stage_k, indices
+    // through stage_v: both are free since the barrier behind the ranking)
+    uint32_t* xk = stage_k;
+    uint32_t* xv = stage_v;
 #pragma unroll
     for (int i = 0; i < EMITF_ITEMS; ++i) {
-      const uint32_t o = wbase + i * WAVE + lane;
       const uint32_t d = k[i] & mask;
       rank[i] = digit_start[d] + wave_hist[wid][d] + rank[i];
-      if (o < n_out) xbuf[rank[i]] = k[i];
+      if (wloc + i * WAVE + lane < count) { xk[rank[i]] = k[i]; xv[rank[i]] = v[i]; }
     }
     __syncthreads();
-    const uint32_t count = min((uint32_t)CHUNK, n_out - c0);
-    uint32_t dst[EMITF_ITEMS];
 #pragma unroll
     for (int i = 0; i < EMITF_ITEMS; ++i) {
       const uint32_t sl = i * EMITF_THREADS + tid;
-      dst[i] = 0xffffffffu;
       if (sl < count) {
-        const uint32_t kk = xbuf[sl];
+        const uint32_t kk = xk[sl];
         const uint32_t d = kk & mask;
         const uint32_t pos = global_base[d] + (sl - digit_start[d]);
         if (pos < capacity) {       // an overflowing frame drops what does not fit (the caller sees num_rendered > capacity)
-          dst[i] = pos;
           keys_out[pos] = kk;
+          vals_out[pos] = xv[sl];
         }
       }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < EMITF_ITEMS; ++i) {
-      const uint32_t o = wbase + i * WAVE + lane;
-      if (o < n_out) xbuf[rank[i]] = v[i];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < EMITF_ITEMS; ++i) {
-      const uint32_t sl = i * EMITF_THREADS + tid;
-      if (dst[i] != 0xffffffffu) vals_out[dst[i]] = xbuf[sl];
     }
   }
 }
@@ -1298,7 +1361,10 @@ void launch_emit_instances(uint32_t v_cap, const uint32_t* total, int grid_x, co
 }
 // ---- fused emission: count_digits + row scan + emit_scatter + the (segmented) second pass of the tile sort ----------------
 bool emit_fused_applies(uint32_t v_cap, int tile_sort_bits) {
-  return !emit_is_wide(v_cap) && sort_passes(tile_sort_bits) == 2;
+  // first digits of at most 7 bits (images of up to 2^15 tiles: 4K): emit_scatter's per-wave digit counters of a wider
+  // digit would push its workgroup beyond 64 KB of LDS; such frames keep the emission + two-pass sort
+  int widths[8];
+  return !emit_is_wide(v_cap) && sort_pass_plan(tile_sort_bits, widths) == 2 && widths[0] <= 7;
 }
 uint32_t emit_fused_cols(uint32_t v_cap) { return (v_cap + (uint32_t)EMIT_GB - 1u) / (uint32_t)EMIT_GB; }
 
@@ -1332,10 +1398,8 @@ void launch_emit_fused_and_sort(uint32_t v_cap, const uint32_t* total, int grid_
   const uint32_t ncols = emit_fused_cols(v_cap);
   const uint32_t mask0 = (1u << w0) - 1u;
   // first digit: the emission itself (what pass 0 would have left in the "b" buffers)
-  if (w0 <= 6)      emit_fused_first_digit<6>(ncols, total, grid_x, d3, d4, bin, mask0, dhist, totals0, keys_b, vals_b, capacity, s);
-  else if (w0 == 7) emit_fused_first_digit<7>(ncols, total, grid_x, d3, d4, bin, mask0, dhist, totals0, keys_b, vals_b, capacity, s);
-  else if (w0 == 8) emit_fused_first_digit<8>(ncols, total, grid_x, d3, d4, bin, mask0, dhist, totals0, keys_b, vals_b, capacity, s);
-  else              emit_fused_first_digit<9>(ncols, total, grid_x, d3, d4, bin, mask0, dhist, totals0, keys_b, vals_b, capacity, s);
+  if (w0 <= 6) emit_fused_first_digit<6>(ncols, total, grid_x, d3, d4, bin, mask0, dhist, totals0, keys_b, vals_b, capacity, s);
+  else         emit_fused_first_digit<7>(ncols, total, grid_x, d3, d4, bin, mask0, dhist, totals0, keys_b, vals_b, capacity, s);
   // second digit: the tile sort's segmented last pass, as sort_pairs_impl runs it
   const int sc = 1 << w0;
   uint2* rr = runs ? runs->runs_rel : nullptr;
