@@ -93,11 +93,8 @@ typedef struct GsrParams {
 } GsrParams;
 
 enum {
-  GSR_DEBUG_NO_MINIBLOCK_CULL = 1, /* forward compositing: every staged instance enters all 16 mini-block lists (the
+  GSR_DEBUG_NO_MINIBLOCK_CULL = 1  /* forward compositing: every staged instance enters all 16 mini-block lists (the
                                       image must not change by a bit: tests/test_gpu_miniblock_cull.py) */
-  GSR_DEBUG_NO_FUSED_EMIT = 2      /* two-level binning: instances emitted in depth order and partitioned by both passes of
-                                      the tile sort (the path of rounds 2-4) instead of leaving the emission partitioned by
-                                      the first digit; the lists must not change by an entry (tests/test_gpu_culled_binning.py) */
 };
 
 enum {

@@ -45,7 +45,6 @@ ACT_SCALE_EXP, ACT_ROT_NORMALIZE, ACT_OPACITY_SIGMOID = 1, 2, 4
 BINNING_TWO_LEVEL, BINNING_KEYS64, BINNING_TWO_LEVEL_CULLED = 0, 1, 2
 DSSIM_ONE_MINUS_MEAN, DSSIM_CLAMPED_HALF = 0, 1
 DEBUG_NO_MINIBLOCK_CULL = 1
-DEBUG_NO_FUSED_EMIT = 2      # two-level binning: the emission + two-pass tile sort of rounds 2-4 (include/gsr.h)
 
 
 # name -> (restype, argtypes); every symbol include/gsr.h declares

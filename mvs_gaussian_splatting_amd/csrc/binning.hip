@@ -266,354 +266,6 @@ __global__ __launch_bounds__(THREADS) void emit_instances_kernel(const uint32_t*
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// Fused emission (round 5; two-pass tile sorts of frames with more than EMIT_WIDE_MAX_BLOCKS emission blocks).
-// The instances used to be written in depth order (emit_instances), read back by the first pass of the tile sort
-// (histogram: 4 R, scatter: 8 R) and written again (8 R).  Here they leave the emission already partitioned by the FIRST
-// digit of the tile id:
-//   count_digits  : per block of EMIT_GB depth-sorted Gaussians, how many of its instances carry each value of the digit
-//                   -> dhist[digit][block] (the matrix radix_hist would have produced, with emission blocks as columns)
-//   radix_rowscan : the tile sort's own row scan over that matrix (row prefixes + digit totals)
-//   emit_scatter  : generates the block's instances in emission order (the load-balanced expansion of emit_instances),
-//                   ranks them by digit (stable: wave match + LDS, as radix_scatter) and writes every (tile, index)
-//                   pair where the first pass would have put it.
-// The second (segmented) pass of the tile sort follows unchanged.  Same lists, bit for bit: a stable partition by the
-// low digit of the emission order is exactly what pass 1 computed.
-// ------------------------------------------------------------------------------------------
-constexpr int EMIT_GB = 1024;                    // depth-sorted Gaussians per block (two per thread)
-constexpr int EMITF_THREADS = SORT_THREADS;      // 512
-constexpr int EMITF_ITEMS = 8;                   // 4096 instances per chunk
-static_assert(EMIT_GB == 2 * EMITF_THREADS, "emitf_load stages two Gaussians per thread");
-
-struct EmitBlockLds {
-  uint32_t incl[EMIT_GB];      // inclusive scan of tiles within the block
-  uint32_t g[EMIT_GB];
-  uint32_t mn[EMIT_GB];        // rect min: x | y << 16
-  uint32_t wh[EMIT_GB];        // rect width | height << 16
-  uint32_t mask[EMIT_GB];      // tile mask (BinInfo::mask)
-  uint32_t wave_tot[EMITF_THREADS / WAVE];
-};
-
-// Stages the block's Gaussians (rect, mask, index, running instance count); returns the block's instance count.
-__device__ inline uint32_t emitf_load(EmitBlockLds& L, uint32_t V, const uint2* __restrict__ dval,
-                                      const BinInfo* __restrict__ bin, int grid_x) {
-  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
-  uint32_t t2[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const uint32_t i = blockIdx.x * (uint32_t)EMIT_GB + 2u * (uint32_t)tid + (uint32_t)u;
-    uint32_t g = 0, mask = 0;
-    uint2 rr = make_uint2(0u, 0u);
-    if (i < V) {
-      const uint2 v = dval[i];
-      g = v.x;
-      if (v.y & PACK_FALLBACK) {
-        const BinInfo bi = bin[g];
-        mask = bi.mask;
-        rr = make_uint2(bi.rect_min, bi.rect_wh);
-      } else {
-        unpack_rect(v.y, (uint32_t)grid_x, rr.x, rr.y, mask);
-      }
-    }
-    t2[u] = i < V ? bin_count(rr.y, mask) : 0u;
-    L.g[2 * tid + u] = g;
-    L.mn[2 * tid + u] = rr.x;
-    L.wh[2 * tid + u] = rr.y;
-    L.mask[2 * tid + u] = mask;
-  }
-  const uint32_t inc = wave_incl_scan_u32(t2[0] + t2[1]);
-  if (lane == WAVE - 1) L.wave_tot[wid] = inc;
-  __syncthreads();
-  uint32_t wbase = 0;
-#pragma unroll
-  for (int w = 0; w < EMITF_THREADS / WAVE; ++w)
-    if (w < wid) wbase += L.wave_tot[w];
-  L.incl[2 * tid] = wbase + inc - t2[1];
-  L.incl[2 * tid + 1] = wbase + inc;
-  __syncthreads();
-  return L.incl[EMIT_GB - 1];
-}
-
-// Tiles of a staged Gaussian, in emission order (y outer, x inner): f(k, tile id) for its k-th instance.
-//   rects of at most MASK_TILES tiles: the set bits of the tile mask, ascending;
-//   larger rects (every tile of the rect): the caller walks k itself (emitf_big_tile).
-template <typename F>
-__device__ inline void emitf_small_tiles(uint32_t mn, uint32_t wh, uint32_t mask, int grid_x, F&& f) {
-  const uint32_t w = max(wh & 0xffffu, 1u);
-  const float rw = 1.0f / (float)w;
-  const uint32_t x0 = mn & 0xffffu, y0 = mn >> 16;
-  uint32_t m = mask, k = 0;
-  while (m) {
-    const uint32_t bit = (uint32_t)__ffs((int)m) - 1u;
-    m &= m - 1u;
-    const uint32_t q = (uint32_t)(((float)bit + 0.5f) * rw);      // bit / w (exact: bit < 32)
-    f(k, (y0 + q) * (uint32_t)grid_x + x0 + (bit - q * w));
-    ++k;
-  }
-}
-__device__ inline uint32_t emitf_big_tile(uint32_t mn, uint32_t wh, uint32_t k, int grid_x) {
-  const uint32_t w = max(wh & 0xffffu, 1u);
-  const uint32_t q = (uint32_t)(((float)k + 0.5f) * (1.0f / (float)w));   // k / w (exact for k < 2^20)
-  return ((mn >> 16) + q) * (uint32_t)grid_x + (mn & 0xffffu) + (k - q * w);
-}
-__device__ inline bool emitf_is_big(uint32_t wh) { return (wh & 0xffffu) * (wh >> 16) > MASK_TILES; }
-
-// The block's Gaussians with more than MASK_TILES tiles, listed for the cooperative loops (order irrelevant: every
-// instance has its own slot).  Returns their number; big_list[] holds their positions in the block.
-__device__ inline uint32_t emitf_list_big(const EmitBlockLds& L, uint16_t* big_list, uint32_t* big_count) {
-  const int tid = threadIdx.x;
-  if (tid == 0) *big_count = 0;
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int j = 2 * tid + u;
-    if (emitf_is_big(L.wh[j])) big_list[atomicAdd(big_count, 1u)] = (uint16_t)j;
-  }
-  __syncthreads();
-  return *big_count;
-}
-
-template <int BITS>
-__global__ __launch_bounds__(EMITF_THREADS) void count_digits_kernel(const uint32_t* __restrict__ total, int grid_x,
-                                                                     const uint2* __restrict__ d3,
-                                                                     const uint2* __restrict__ d4,
-                                                                     const BinInfo* __restrict__ bin, uint32_t mask,
-                                                                     uint32_t ncols, uint32_t* __restrict__ dhist) {
-  constexpr int RADIX = 1 << BITS;
-  __shared__ EmitBlockLds L;
-  __shared__ uint32_t h[RADIX];
-  __shared__ uint16_t big_list[EMIT_GB];
-  __shared__ uint32_t big_count;
-  const uint32_t V = total[TOTAL_V];
-  const int tid = threadIdx.x;
-#pragma unroll
-  for (int d = tid; d < RADIX; d += EMITF_THREADS) h[d] = 0;
-  if (blockIdx.x * (uint32_t)EMIT_GB < V) {      // (uniform) blocks past the count publish an all-zero column: the row scan
-    const uint2* __restrict__ dval = total[TOTAL_TOP_PASS_N] ? d4 : d3;      // runs over the columns of the capacity
-    emitf_load(L, V, dval, bin, grid_x);                                     // (its two barriers also cover h[])
-    // every lane counts the tiles of its two Gaussians (2.1 each on the bench cloud); the few large rects are walked by
-    // the whole block
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int j = 2 * tid + u;
-      const uint32_t wh = L.wh[j];
-      if (!emitf_is_big(wh))
-        emitf_small_tiles(L.mn[j], wh, L.mask[j], grid_x, [&](uint32_t, uint32_t tile) { atomicAdd(&h[tile & mask], 1u); });
-    }
-    const uint32_t nbig = emitf_list_big(L, big_list, &big_count);
-    for (uint32_t b = 0; b < nbig; ++b) {
-      const int j = big_list[b];
-      const uint32_t mn = L.mn[j], wh = L.wh[j];
-      const uint32_t n = (wh & 0xffffu) * (wh >> 16);
-      for (uint32_t k = (uint32_t)tid; k < n; k += EMITF_THREADS) atomicAdd(&h[emitf_big_tile(mn, wh, k, grid_x) & mask], 1u);
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int d = tid; d < RADIX; d += EMITF_THREADS) dhist[(size_t)d * ncols + blockIdx.x] = h[d];
-}
-
-template <int BITS>
-__global__ __launch_bounds__(EMITF_THREADS) void emit_scatter_kernel(const uint32_t* __restrict__ total, int grid_x,
-                                                                     const uint2* __restrict__ d3,
-                                                                     const uint2* __restrict__ d4,
-                                                                     const BinInfo* __restrict__ bin, uint32_t mask,
-                                                                     uint32_t ncols, const uint32_t* __restrict__ dhist,
-                                                                     const uint32_t* __restrict__ totals,
-                                                                     uint32_t* __restrict__ keys_out,
-                                                                     uint32_t* __restrict__ vals_out, uint32_t capacity) {
-  constexpr int RADIX = 1 << BITS;
-  constexpr int NW = EMITF_THREADS / WAVE;
-  constexpr int CHUNK = EMITF_THREADS * EMITF_ITEMS;
-  const uint32_t V = total[TOTAL_V];
-  if (blockIdx.x * (uint32_t)EMIT_GB >= V) return;      // grid sized for a capacity (uniform exit: no barrier crossed)
-  const uint2* __restrict__ dval = total[TOTAL_TOP_PASS_N] ? d4 : d3;
-  __shared__ EmitBlockLds L;
-  // the chunk's instances in emission order (every Gaussian writes its own: no search per output slot); the tile ids'
-  // array then serves as the exchange buffer of the scatter
-  __shared__ uint32_t stage_k[CHUNK];
-  __shared__ uint32_t stage_v[CHUNK];
-  __shared__ uint32_t wave_hist[NW][RADIX];    // per-wave digit counts, then exclusive wave prefixes
-  __shared__ uint32_t digit_start[RADIX];      // first local slot of every digit (this chunk)
-  __shared__ uint32_t global_base[RADIX];      // global position of the chunk's first item of the digit
-  __shared__ uint32_t block_base[RADIX];       // ... of the BLOCK's first item of the digit (digit base + row prefix)
-  __shared__ uint32_t carried[RADIX];          // items of the digit in the block's earlier chunks
-  __shared__ uint32_t scan_tmp[NW];
-  __shared__ uint16_t big_list[EMIT_GB];
-  __shared__ uint32_t big_count;
-  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
-  constexpr int BPT = RADIX >= EMITF_THREADS ? RADIX / EMITF_THREADS : 1;
-  const bool owner = tid * BPT < RADIX;
-
-  const uint32_t n_out = emitf_load(L, V, dval, bin, grid_x);
-  const uint32_t nbig = emitf_list_big(L, big_list, &big_count);
-  {   // digit bases = exclusive scan of the digit totals; + this block's row prefix (the scanned dhist column)
-    uint32_t tot[BPT], tmine = 0;
-#pragma unroll
-    for (int e = 0; e < BPT; ++e) {
-      tot[e] = owner ? totals[tid * BPT + e] : 0u;
-      tmine += tot[e];
-    }
-    const uint32_t t_inc = wave_incl_scan_u32(tmine);
-    if (lane == WAVE - 1) scan_tmp[wid] = t_inc;
-    __syncthreads();
-    uint32_t toff = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w)
-      if (w < wid) toff += scan_tmp[w];
-    uint32_t texcl = toff + t_inc - tmine;
-    if (owner) {
-#pragma unroll
-      for (int e = 0; e < BPT; ++e) {
-        const int d = tid * BPT + e;
-        block_base[d] = texcl + dhist[(size_t)d * ncols + blockIdx.x];
-        carried[d] = 0;
-        texcl += tot[e];
-      }
-    }
-  }
-  // this thread's two Gaussians (kept in registers across the chunks)
-  uint32_t my_first[2], my_n[2], my_mn[2], my_wh[2], my_mask[2], my_g[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int j = 2 * tid + u;
-    my_wh[u] = L.wh[j];
-    my_mn[u] = L.mn[j];
-    my_mask[u] = L.mask[j];
-    my_g[u] = L.g[j];
-    const uint32_t end = L.incl[j];
-    my_first[u] = j ? L.incl[j - 1] : 0u;
-    my_n[u] = emitf_is_big(my_wh[u]) ? 0u : end - my_first[u];      // 0: nothing to do on the per-lane path
-  }
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  for (uint32_t c0 = 0; c0 < n_out; c0 += CHUNK) {
-    __syncthreads();       // the previous chunk is done with the stages / wave_hist / digit_start; block_base / carried are written
-#pragma unroll
-    for (int w = 0; w < NW; ++w)
-#pragma unroll
-      for (int d = tid; d < RADIX; d += EMITF_THREADS) wave_hist[w][d] = 0;
-    // ---- the chunk's instances, slot by slot: every Gaussian that reaches into [c0, c0 + CHUNK) writes its own ----
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (my_n[u] && my_first[u] < c0 + CHUNK && my_first[u] + my_n[u] > c0) {
-        const uint32_t first = my_first[u], g = my_g[u];
-        emitf_small_tiles(my_mn[u], my_wh[u], my_mask[u], grid_x, [&](uint32_t k, uint32_t tile) {
-          const uint32_t sl = first + k - c0;      // wraps for slots in front of the window
-          if (sl < (uint32_t)CHUNK) { stage_k[sl] = tile; stage_v[sl] = g; }
-        });
-      }
-    }
-    for (uint32_t b = 0; b < nbig; ++b) {         // large rects: the whole block walks the part inside the window
-      const int j = big_list[b];
-      const uint32_t first = j ? L.incl[j - 1] : 0u, end = L.incl[j];
-      if (first >= c0 + CHUNK || end <= c0) continue;     // (uniform)
-      const uint32_t mn = L.mn[j], wh = L.wh[j], g = L.g[j];
-      const uint32_t lo = max(first, c0), hi = min(end, c0 + (uint32_t)CHUNK);
-      for (uint32_t o = lo + (uint32_t)tid; o < hi; o += EMITF_THREADS) {
-        stage_k[o - c0] = emitf_big_tile(mn, wh, o - first, grid_x);
-        stage_v[o - c0] = g;
-      }
-    }
-    __syncthreads();
-    // item i of lane l of wave w is output slot c0 + w * 512 + i * 64 + l: (i, l) lexicographic == emission order
-    const uint32_t wloc = (uint32_t)wid * (WAVE * EMITF_ITEMS);
-    const uint32_t count = min((uint32_t)CHUNK, n_out - c0);
-    uint32_t k[EMITF_ITEMS], v[EMITF_ITEMS], rank[EMITF_ITEMS];
-#pragma unroll
-    for (int i = 0; i < EMITF_ITEMS; ++i) {
-      const uint32_t sl = min(wloc + i * WAVE + lane, count - 1u);
-      k[i] = stage_k[sl];
-      v[i] = stage_v[sl];
-    }
-    // stable rank of every item among the wave's items with the same digit (radix_scatter_kernel's wave match)
-#pragma unroll
-    for (int i = 0; i < EMITF_ITEMS; ++i) {
-      const bool ok = wloc + i * WAVE + lane < count;
-      const uint32_t d = k[i] & mask;
-      unsigned long long peers = __ballot(ok);
-      if (!ok) peers = ~peers;
-#pragma unroll
-      for (int b = 0; b < BITS; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const unsigned long long bal = __ballot(bit);
-        peers &= bit ? bal : ~bal;
-      }
-      const uint32_t cnt = (uint32_t)__popcll(peers);
-      const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
-      uint32_t old = 0;
-      if (ok) {
-        old = wave_hist[wid][d];
-        if (before == 0) wave_hist[wid][d] = old + cnt;
-      }
-      rank[i] = old + before;
-    }
-    __syncthreads();       // also: every read of the stages is done
-    {   // digit totals of the chunk over the waves -> exclusive wave prefixes, local digit starts, global positions
-      uint32_t dsum[BPT], mine = 0;
-#pragma unroll
-      for (int e = 0; e < BPT; ++e) {
-        const int d = tid * BPT + e;
-        uint32_t run = 0;
-        dsum[e] = 0;
-        if (owner) {
-#pragma unroll
-          for (int w = 0; w < NW; ++w) {
-            const uint32_t c = wave_hist[w][d];
-            wave_hist[w][d] = run;
-            run += c;
-          }
-          dsum[e] = run;
-          mine += run;
-        }
-      }
-      const uint32_t inc = wave_incl_scan_u32(mine);
-      if (lane == WAVE - 1) scan_tmp[wid] = inc;
-      __syncthreads();
-      uint32_t woff = 0;
-#pragma unroll
-      for (int w = 0; w < NW; ++w)
-        if (w < wid) woff += scan_tmp[w];
-      uint32_t excl = woff + inc - mine;
-      if (owner) {
-#pragma unroll
-        for (int e = 0; e < BPT; ++e) {
-          const int d = tid * BPT + e;
-          digit_start[d] = excl;
-          const uint32_t done = carried[d];
-          global_base[d] = block_base[d] + done;
-          carried[d] = done + dsum[e];
-          excl += dsum[e];
-        }
-      }
-    }
-    __syncthreads();
-    // exchange through LDS so that every digit's run leaves the block contiguously (tile ids through stage_k, indices
-    // through stage_v: both are free since the barrier behind the ranking)
-    uint32_t* xk = stage_k;
-    uint32_t* xv = stage_v;
-#pragma unroll
-    for (int i = 0; i < EMITF_ITEMS; ++i) {
-      const uint32_t d = k[i] & mask;
-      rank[i] = digit_start[d] + wave_hist[wid][d] + rank[i];
-      if (wloc + i * WAVE + lane < count) { xk[rank[i]] = k[i]; xv[rank[i]] = v[i]; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < EMITF_ITEMS; ++i) {
-      const uint32_t sl = i * EMITF_THREADS + tid;
-      if (sl < count) {
-        const uint32_t kk = xk[sl];
-        const uint32_t d = kk & mask;
-        const uint32_t pos = global_base[d] + (sl - digit_start[d]);
-        if (pos < capacity) {       // an overflowing frame drops what does not fit (the caller sees num_rendered > capacity)
-          keys_out[pos] = kk;
-          vals_out[pos] = xv[sl];
-        }
-      }
-    }
-  }
-}
-
 // debug: the 64-bit keys a (tile, depth) sort would have produced, rebuilt from the two-level result
 __global__ __launch_bounds__(256) void reconstruct_keys_kernel(uint32_t R, uint32_t P,
                                                                const uint32_t* __restrict__ tile_sorted,
@@ -1358,63 +1010,6 @@ void launch_emit_instances(uint32_t v_cap, const uint32_t* total, int grid_x, co
   else
     hipLaunchKernelGGL(emit_instances_kernel<PRE_BLOCK>, dim3(nb), dim3(PRE_BLOCK), 0, s, total, grid_x, d3, d4, bin,
                        block_offs2, inst_tile, inst_g, capacity);
-}
-// ---- fused emission: count_digits + row scan + emit_scatter + the (segmented) second pass of the tile sort ----------------
-bool emit_fused_applies(uint32_t v_cap, int tile_sort_bits) {
-  // first digits of at most 7 bits (images of up to 2^15 tiles: 4K): emit_scatter's per-wave digit counters of a wider
-  // digit would push its workgroup beyond 64 KB of LDS; such frames keep the emission + two-pass sort
-  int widths[8];
-  return !emit_is_wide(v_cap) && sort_pass_plan(tile_sort_bits, widths) == 2 && widths[0] <= 7;
-}
-uint32_t emit_fused_cols(uint32_t v_cap) { return (v_cap + (uint32_t)EMIT_GB - 1u) / (uint32_t)EMIT_GB; }
-
-template <int BITS>
-static void emit_fused_first_digit(uint32_t ncols, const uint32_t* total, int grid_x, const uint2* d3, const uint2* d4,
-                                   const BinInfo* bin, uint32_t mask, uint32_t* dhist, uint32_t* totals0,
-                                   uint32_t* keys_out, uint32_t* vals_out, uint32_t capacity, hipStream_t s) {
-  hipLaunchKernelGGL((count_digits_kernel<BITS>), dim3(ncols), dim3(EMITF_THREADS), 0, s, total, grid_x, d3, d4, bin, mask,
-                     ncols, dhist);
-  // the tile sort's own row scan over the emission blocks' matrix: row prefixes in place + digit totals (always
-  // published: a frame without instances leaves all-zero totals, which the segmented pass and the ranges need)
-  hipLaunchKernelGGL(radix_rowscan_kernel, dim3(1 << BITS), dim3(256), 0, s, dhist, ncols, totals0,
-                     (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0, (uint2*)nullptr, 0, 0u);
-  hipLaunchKernelGGL((emit_scatter_kernel<BITS>), dim3(ncols), dim3(EMITF_THREADS), 0, s, total, grid_x, d3, d4, bin, mask,
-                     ncols, dhist, totals0, keys_out, vals_out, capacity);
-}
-
-// Enqueues the whole chain; the sorted (tile, index) pairs end in (keys_a, vals_a).  Requires emit_fused_applies().
-void launch_emit_fused_and_sort(uint32_t v_cap, const uint32_t* total, int grid_x, const uint2* d3, const uint2* d4,
-                                const BinInfo* bin, uint32_t* dhist, uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b,
-                                uint32_t* vals_b, uint32_t r_cap, int end_bit, void* scratch, uint32_t capacity,
-                                hipStream_t s, const uint32_t* r_dev, SortedRuns* runs) {
-  const SortLayout L(r_cap);
-  uint32_t* hist = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + L.hist);
-  uint32_t* totals0 = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + L.totals);
-  uint32_t* totals1 = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch) + L.totals_odd);
-  int widths[8];
-  const int passes = sort_pass_plan(end_bit, widths);
-  (void)passes;      // == 2 (emit_fused_applies)
-  const int w0 = widths[0], w1 = widths[1];
-  const uint32_t ncols = emit_fused_cols(v_cap);
-  const uint32_t mask0 = (1u << w0) - 1u;
-  // first digit: the emission itself (what pass 0 would have left in the "b" buffers)
-  if (w0 <= 6) emit_fused_first_digit<6>(ncols, total, grid_x, d3, d4, bin, mask0, dhist, totals0, keys_b, vals_b, capacity, s);
-  else         emit_fused_first_digit<7>(ncols, total, grid_x, d3, d4, bin, mask0, dhist, totals0, keys_b, vals_b, capacity, s);
-  // second digit: the tile sort's segmented last pass, as sort_pairs_impl runs it
-  const int sc = 1 << w0;
-  uint2* rr = runs ? runs->runs_rel : nullptr;
-  const uint32_t nk = runs ? runs->n_keys : 0u;
-  if (w1 <= 6)      sort_pass<uint32_t, uint32_t, 6>(keys_b, vals_b, keys_a, vals_a, r_cap, r_dev, w0, w1, L, hist, totals1, s, totals0, sc, rr, w0, nk);
-  else if (w1 == 7) sort_pass<uint32_t, uint32_t, 7>(keys_b, vals_b, keys_a, vals_a, r_cap, r_dev, w0, w1, L, hist, totals1, s, totals0, sc, rr, w0, nk);
-  else if (w1 == 8) sort_pass<uint32_t, uint32_t, 8>(keys_b, vals_b, keys_a, vals_a, r_cap, r_dev, w0, w1, L, hist, totals1, s, totals0, sc, rr, w0, nk);
-  else              sort_pass<uint32_t, uint32_t, 9>(keys_b, vals_b, keys_a, vals_a, r_cap, r_dev, w0, w1, L, hist, totals1, s, totals0, sc, rr, w0, nk);
-  if (runs) {
-    runs->valid = true;
-    runs->totals_last = totals1;
-    runs->relative = true;
-    runs->lo_bits = w0;
-    runs->hi_bits = w1;
-  }
 }
 void launch_reconstruct_keys(uint32_t R, uint32_t P, const uint32_t* tile_sorted, const uint32_t* point_list,
                              const BinInfo* bin, uint64_t* keys, hipStream_t s) {

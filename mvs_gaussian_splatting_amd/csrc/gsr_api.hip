@@ -327,27 +327,20 @@ static int enqueue_stage2(const GsrParams* p, void* geom_ws, void* bin_ws, size_
       const uint2* d3 = at<uint2>(geom_ws, in_b3 ? L.didx_b : L.didx_a);
       const uint2* d4 = at<uint2>(geom_ws, in_b3 ? L.didx_a : L.didx_b);
       const uint32_t cap = device_counts ? r_cap : 0xffffffffu;
+      {
+        StageTimer t(p, GSR_STAGE_DUPLICATE, s);   // instances emitted in depth order
+        launch_count_tiles(v_cap, total, d3, d4, bin, bsum2, s);
+        if (emit_is_wide(v_cap)) {      // small frame: the emission sums the block totals itself, no scan launch
+          launch_emit_instances(v_cap, total, I.grid_x, d3, d4, bin, bsum2, ita, iga, cap, s);
+        } else {
+          launch_scan_block_sums(bsum2, boffs2, boffs2 + B.nblocks2 + 1, nullptr, nullptr, nullptr, (int)B.nblocks2, s);
+          launch_emit_instances(v_cap, total, I.grid_x, d3, d4, bin, boffs2, ita, iga, cap, s);
+        }
+      }
+      if (int rc = check(p, s, "emit_instances")) return rc;
       const uint32_t* r_dev = device_counts ? total + TOTAL_R_CLAMPED : nullptr;
       bool in_b;
-      if (emit_fused_applies(v_cap, tb) && !(p->debug_flags & GSR_DEBUG_NO_FUSED_EMIT)) {
-        // the instances leave the emission partitioned by the first digit of the tile id (binning.hip: fused emission);
-        // the tile sort's second pass follows.  One stage for the timers: the emission IS the sort's first pass.
-        StageTimer t(p, GSR_STAGE_SORT, s);
-        launch_emit_fused_and_sort(v_cap, total, I.grid_x, d3, d4, bin, at<uint32_t>(bin_ws, B.dhist), ita, iga, itb, igb,
-                                   r_cap, tb, at<char>(bin_ws, B.sort), cap, s, r_dev, &runs);
-        in_b = false;
-      } else {
-        {
-          StageTimer t(p, GSR_STAGE_DUPLICATE, s);   // instances emitted in depth order
-          launch_count_tiles(v_cap, total, d3, d4, bin, bsum2, s);
-          if (emit_is_wide(v_cap)) {      // small frame: the emission sums the block totals itself, no scan launch
-            launch_emit_instances(v_cap, total, I.grid_x, d3, d4, bin, bsum2, ita, iga, cap, s);
-          } else {
-            launch_scan_block_sums(bsum2, boffs2, boffs2 + B.nblocks2 + 1, nullptr, nullptr, nullptr, (int)B.nblocks2, s);
-            launch_emit_instances(v_cap, total, I.grid_x, d3, d4, bin, boffs2, ita, iga, cap, s);
-          }
-        }
-        if (int rc = check(p, s, "emit_instances")) return rc;
+      {
         StageTimer t(p, GSR_STAGE_SORT, s);     // stable partition by tile id
         in_b = launch_sort_pairs_u32(ita, iga, itb, igb, r_cap, tb, at<char>(bin_ws, B.sort), s, r_dev, &runs);
       }

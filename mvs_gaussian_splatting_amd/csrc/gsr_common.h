@@ -205,7 +205,7 @@ struct BinLayout {
   // mode 1
   size_t keys_a, keys_b, vals_a, vals_b;
   // mode 0
-  size_t bsum2, boffs2, itile_a, itile_b, ig_a, ig_b, dhist;
+  size_t bsum2, boffs2, itile_a, itile_b, ig_a, ig_b;
   size_t sort, bytes;
   uint32_t nblocks2;
   __host__ __device__ BinLayout(uint32_t R, uint32_t V, int mode) {
@@ -213,7 +213,7 @@ struct BinLayout {
     nblocks2 = (uint32_t)((v + PRE_BLOCK - 1) / PRE_BLOCK);
     size_t o = 0;
     keys_a = keys_b = vals_a = vals_b = 0;
-    bsum2 = boffs2 = itile_a = itile_b = ig_a = ig_b = dhist = 0;
+    bsum2 = boffs2 = itile_a = itile_b = ig_a = ig_b = 0;
     if (mode == 1) {
       keys_a = o; o = align_up(o + 8 * n, 256);
       keys_b = o; o = align_up(o + 8 * n, 256);
@@ -228,8 +228,6 @@ struct BinLayout {
       ig_a = o;   o = align_up(o + 4 * n, 256);
       ig_b = o;   o = align_up(o + 4 * n, 256);
       sort = o;   o = align_up(o + SortLayout((uint32_t)n).bytes, 256);
-      // fused emission (binning.hip): first-digit counts of every block of 1024 depth-sorted Gaussians, [digit][block]
-      dhist = o;  o = align_up(o + 4 * (size_t)RADIX * ((v + 1023) / 1024 + 1), 256);
     }
     bytes = o;
   }

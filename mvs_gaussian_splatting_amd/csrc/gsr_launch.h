@@ -81,15 +81,6 @@ inline bool emit_is_wide(uint32_t v_cap) { return (v_cap + PRE_BLOCK - 1) / PRE_
 void launch_emit_instances(uint32_t v_cap, const uint32_t* total, int grid_x, const uint2* d3, const uint2* d4,
                            const BinInfo* bin, const uint32_t* block_offs2, uint32_t* inst_tile, uint32_t* inst_g,
                            uint32_t capacity, hipStream_t s);
-// Fused emission (binning.hip): for two-pass tile sorts of frames with more than EMIT_WIDE_MAX_BLOCKS emission blocks the
-// instances leave the emission partitioned by the first digit of the tile id (count_digits + row scan + emit_scatter), the
-// segmented second pass follows; the sorted pairs end in (keys_a, vals_a).  dhist: 4 * RADIX * emit_fused_cols(v_cap) bytes.
-bool emit_fused_applies(uint32_t v_cap, int tile_sort_bits);
-uint32_t emit_fused_cols(uint32_t v_cap);
-void launch_emit_fused_and_sort(uint32_t v_cap, const uint32_t* total, int grid_x, const uint2* d3, const uint2* d4,
-                                const BinInfo* bin, uint32_t* dhist, uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b,
-                                uint32_t* vals_b, uint32_t r_cap, int end_bit, void* scratch, uint32_t capacity,
-                                hipStream_t s, const uint32_t* r_dev, SortedRuns* runs);
 void launch_reconstruct_keys(uint32_t R, uint32_t P, const uint32_t* tile_sorted, const uint32_t* point_list,
                              const BinInfo* bin, uint64_t* keys, hipStream_t s);
 

@@ -168,56 +168,3 @@ def test_all_binning_modes_agree_at_4k(dev, W, H, P, f):
         assert torch.equal(outs[0]["radii"], o["radii"])
     k = outs[2]["keys"]
     assert np.all(k[1:] >= k[:-1]) and int(k[-1] >> np.uint64(32)) < ((W + 15) // 16) * ((H + 15) // 16)
-
-
-# ---- fused emission (round 5): the instances leave the emission partitioned by the tile sort's first digit ---------------
-def _fwd(dev, st, model, mode, **extra):
-    from gpu_util import forward_with_state
-    return forward_with_state(dev, st, model.get_xyz, model.get_opacity, shs=model.get_features, scales=model.get_scaling,
-                              rotations=model.get_rotation, binning_mode=mode, **extra)
-
-
-@pytest.mark.parametrize("scene", ["C3", "heavy_tail_400k", "wide_image"])
-def test_fused_emission_leaves_the_lists_of_the_two_pass_tile_sort(dev, scene):
-    """Frames with more than 512 emission blocks and a two-pass tile sort take the fused emission (count_digits + row scan
-    + emit_scatter + the sort's second pass).  With GSR_DEBUG_NO_FUSED_EMIT the frame takes the emission + two-pass sort of
-    rounds 2-4: sorted tile ids, point lists, ranges, image and per-pixel state must be IDENTICAL, in both two-level modes,
-    through the two-call forward and through gsr_forward (grids sized for a capacity, counts read on the device, P as the
-    visible-Gaussian capacity).  Scenes: BASELINE C3; a heavy-tailed cloud (rects beyond the packed payload and the
-    32-tile mask: the BinInfo fall-back of the emission; blocks of several chunks); a 4K-wide image (15 tile bits: 7 + 8)."""
-    from gpu_util import product_settings
-    from mvs_gaussian_splatting_amd import _lib, rasterizer
-    from mvs_gaussian_splatting_amd.synthetic import CONFIGS, SceneConfig, make_scene, make_heavy_tail_model, orbit_camera
-    if scene == "C3":
-        cfg = CONFIGS["C3"]
-        model, cam, bg, _ = make_scene(cfg)
-        deg = cfg.sh_degree
-    elif scene == "heavy_tail_400k":
-        deg = 1
-        model = make_heavy_tail_model(400_000, deg, seed=5, log_footprint_mean=math.log(0.0013))
-        cam = orbit_camera(0, 8, 1920, 1080, 1200.0, 1200.0)
-        bg = torch.zeros(3)
-    else:
-        cfg = SceneConfig("wide", 600_000, 1, 3840, 2160, 2400.0, 2400.0, math.log(0.008))
-        model, cam, bg, _ = make_scene(cfg)
-        deg = 1
-    st = product_settings(cam, bg, deg, dev)
-    for mode in (TWO_LEVEL, CULLED):
-        prev = rasterizer.set_debug_flags(_lib.DEBUG_NO_FUSED_EMIT)
-        try:
-            ref = _fwd(dev, st, model, mode)
-        finally:
-            rasterizer.set_debug_flags(prev)
-        assert ref["V"] > 512 * 256, "the scene must have more than 512 emission blocks"
-        for extra in ({}, {"sync_free_capacity": int(1.3 * ref["R"])}):
-            out = _fwd(dev, st, model, mode, **extra)
-            assert (out["R"], out["V"]) == (ref["R"], ref["V"])
-            assert np.array_equal(out["keys"], ref["keys"]), (scene, mode, extra)
-            assert np.array_equal(out["point_list"], ref["point_list"]), (scene, mode, extra)
-            assert np.array_equal(out["ranges"], ref["ranges"])
-            for k in ("color", "final_T", "n_contrib", "radii"):
-                assert torch.equal(out[k], ref[k]), k
-    if scene == "heavy_tail_400k":
-        tiles = ref["tiles"]
-        assert int((tiles > 32).sum()) > 100 and int((tiles > 4096).sum()) >= 0
-        assert ref["R"] > 4 * ref["V"]          # blocks of 1024 Gaussians emit more than one 4096-instance chunk
